@@ -1,0 +1,146 @@
+/*
+ * ipm_hip.h -- C ABI of libipm_hip.so: the MI355X (gfx950) Newton/KKT hot path of a
+ * Mehrotra predictor-corrector interior-point LP solver.
+ *
+ * Drop-in boundary for payakorn/InteriorPointMethod.  The reference has no FFI;
+ * its seams are plain Python calls.  Each entry point below names
+ * the reference code it replaces (paths relative to the reference repo root):
+ *
+ *   solver seam     interior_sparse   main.py:760-815   /  interior  main.py:707-757
+ *   direction seam  direction_predicted_sparse(method="normal")  main.py:197,221-229
+ *                   direction_corrected_sparse                  main.py:247-269
+ *   linear seam     solve_linear                                 main.py:176-182
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  All arithmetic is
+ * IEEE fp64.  Every function returns an int status (IPM_OK == 0, < 0 error) and
+ * never throws or aborts.  Buffers passed in are owned by the caller; device
+ * scratch lives in a workspace that is either supplied by the caller (a device
+ * pointer, e.g. the data_ptr() of a torch.uint8 tensor) or hipMalloc'ed by the
+ * library when the caller passes NULL.  A handle is bound to one HIP device and
+ * one stream, is not thread-safe; handles on distinct devices are independent.
+ */
+#ifndef IPM_HIP_H
+#define IPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPM_ABI_VERSION 1
+
+/* return codes */
+enum {
+    IPM_OK = 0,
+    IPM_ERR_INVALID_ARG = -1,
+    IPM_ERR_HIP = -2,          /* a HIP runtime call failed; see ipm_last_error() */
+    IPM_ERR_NO_DEVICE = -3,
+    IPM_ERR_WORKSPACE = -4,    /* caller workspace too small / misaligned */
+    IPM_ERR_STATE = -5,        /* call order violated (e.g. solve before set_A) */
+    IPM_ERR_INVALID_INPUT = -6 /* non-finite entries in A, b or c (8 Netlib files) */
+};
+
+/* solver status written to ipm_stats.status (reference semantics in comments) */
+enum {
+    IPM_STATUS_RUNNING = 0,    /* stop test still true                     main.py:780 */
+    IPM_STATUS_CONVERGED = 1,  /* check_optimality() returned False        main.py:162-173 */
+    IPM_STATUS_MAX_ITER = 2,   /* k reached the cap (5000/50000)           main.py:725,780 */
+    IPM_STATUS_NAN = 3         /* non-finite iterate / residual            main.py:1141-1148 */
+};
+
+typedef struct ipm_handle ipm_handle;
+
+typedef struct ipm_options {
+    double eta;              /* step damping, reference constant 0.91        main.py:607 */
+    double pivot_guard_eps;  /* pivot <= eps*max diag(B) -> pivot_guard_big   */
+    double pivot_guard_big;  /* replacement pivot, default 1e64 */
+    int32_t check_every;     /* iterations enqueued between host status reads (>=1) */
+    int32_t reserved0;
+    int64_t reserved1;
+} ipm_options;
+
+/* per-solve statistics; norms use the reference's scaling (main.py:170-171) */
+typedef struct ipm_stats {
+    int32_t status;          /* IPM_STATUS_* */
+    int32_t iterations;      /* k: completed predictor-corrector steps */
+    int32_t pivots_fixed;    /* total Cholesky pivots replaced by the guard */
+    int32_t reserved;
+    double objective;        /* c^T x                                        main.py:815 */
+    double rp_norm;          /* ||Ax-b||_2 */
+    double rd_norm;          /* ||A^T y + s - c||_2 */
+    double gap;              /* x^T s */
+    double b_norm, c_norm;   /* ||b||_2, ||c||_2 */
+    double mu, mu_aff, sigma;            /* last iteration           main.py:588-601 */
+    double alpha_aff_p, alpha_aff_d;     /* predictor ratio tests    main.py:305-322 */
+    double alpha_p, alpha_d;             /* damped step lengths      main.py:604-626 */
+    double solve_ms;         /* device time of the last ipm_solve/ipm_iterate (HIP events) */
+} ipm_stats;
+
+/* ---- library ---------------------------------------------------------------------- */
+int ipm_abi_version(void);
+int ipm_device_count(int* count);
+void ipm_default_options(ipm_options* opts);
+
+/* ---- handle ----------------------------------------------------------------------- */
+/* Bytes of device workspace a handle for an m x n problem needs. */
+int ipm_workspace_bytes(int64_t m, int64_t n, size_t* bytes);
+
+/* workspace == NULL: the library allocates (and frees in ipm_destroy).
+ * stream == NULL: the library creates its own stream on `device`. */
+int ipm_create(int device, int64_t m, int64_t n, const ipm_options* opts,
+               void* workspace, size_t workspace_bytes, void* stream, ipm_handle** out);
+int ipm_destroy(ipm_handle* h);
+const char* ipm_last_error(const ipm_handle* h);   /* also valid with h == NULL */
+
+/* ---- problem data (replaces the arguments of interior_sparse, main.py:760) -------- */
+/* Row-major m x n fp64 matrix with leading dimension ld (elements). is_device: the
+ * pointer is device memory on the handle's device (copied device-to-device). */
+int ipm_set_A_dense(ipm_handle* h, const double* A, int64_t ld, int is_device);
+/* CSC triplets as scipy.sparse.csc_matrix holds them (sparse_interior.py:215); host memory. */
+int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t* rowind,
+                  const double* val, int64_t nnz);
+int ipm_set_bc(ipm_handle* h, const double* b, const double* c);        /* host, length m / n */
+
+/* ---- iterate (x, y, s) ------------------------------------------------------------- */
+int ipm_set_state(ipm_handle* h, const double* x, const double* y, const double* s);  /* host */
+int ipm_get_state(ipm_handle* h, double* x, double* y, double* s);                    /* host */
+/* x = s = 1, y = y0: sparse_interior.py:193-200 (y0=1) / main.py:287-302 (y0=0) */
+int ipm_init_state(ipm_handle* h, double y0);
+
+/* ---- direction seam (main.py:197 / :247) ------------------------------------------- */
+/* corrector == 0: predictor direction at the current state (forms and factors A D^2 A^T).
+ * corrector == 1: corrector direction; requires a preceding predictor call at the same
+ * state (reuses its factor and affine direction).  Outputs are host arrays (may be NULL). */
+int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, double* dy, double* ds,
+                         ipm_stats* stats);
+
+/* ---- solver seam ------------------------------------------------------------------- */
+/* Run exactly n_steps predictor-corrector iterations from the current state.  The stop
+ * test is evaluated (stats) but not acted on: this is the benchmark entry point. */
+int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats);
+/* Loop of interior_sparse: stop test first, then one iteration, until the test fails or
+ * max_iter iterations were taken.  tol_p/tol_d/tol_gap = e1/e2/e3 of main.py:772-774. */
+int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t max_iter,
+              ipm_stats* stats);
+
+/* ---- linear-solve seam (main.py:176-182) and kernel-level entry points ------------- */
+/* Solve B z = rhs for a dense SPD m x m host matrix by the blocked guarded Cholesky
+ * (m = the handle's m).  z may alias rhs.  pivots_fixed may be NULL. */
+int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, const double* rhs, double* z,
+                     int32_t* pivots_fixed);
+/* B = A diag(d) A^T (d on the host, length n); full symmetric m x m written to host B. */
+int ipm_form_normal_matrix(ipm_handle* h, const double* d, double* B, int64_t ldb);
+/* Cholesky factor of the handle's current normal matrix; lower triangle to host L. */
+int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl);
+/* Timing of the device phases of the last ipm_iterate call, milliseconds per iteration:
+ * out[0]=form A D^2 A^T, out[1]=factor, out[2]=triangular solves, out[3]=everything else.
+ * Only filled when profiling was requested with ipm_set_profiling(h, 1). */
+int ipm_set_profiling(ipm_handle* h, int enable);
+int ipm_get_phase_ms(ipm_handle* h, double out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPM_HIP_H */

@@ -1,0 +1,258 @@
+"""Host-side mirror of the reference's interior-point call surface, running on libipm_hip.so.
+
+Same names and argument meaning as the reference (payakorn/InteriorPointMethod):
+
+    solve(A, b, c)                      -> (x, y, s)      the north-star seam
+    interior_sparse(A, b, c, cTlb, tol) -> objective - cTlb          main.py:760-815
+    interior(A, b, c, tol)              -> objective                 main.py:707-757 (returns None there)
+    direction_predicted_sparse(..., method="normal") -> (dx, dy, ds) main.py:197, 221-229
+    direction_corrected_sparse(...)     -> (dx, dy, ds)              main.py:247-269
+    solve_linear(B, rhs)                -> (N, 1)                    main.py:176-182
+
+A is a scipy sparse matrix (any format; the reference passes CSC) or a dense array; b, c are
+(len,) or (len, 1) of any numeric dtype (the .mat files hold int16/uint8) and are
+cast to float64 here.  Outputs are fresh (len, 1) float64 arrays like the reference's.
+PyTorch is used only to own the device workspace and the stream; all arithmetic is HIP.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+try:  # scipy is optional on the host side (dense inputs work without it)
+    from scipy import sparse as _sp
+except Exception:  # pragma: no cover
+    _sp = None
+
+STATUS_NAMES = {0: "running", 1: "converged", 2: "max_iter", 3: "nan"}
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _col(v, n, name):
+    v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+    if v.shape[0] != n:
+        raise ValueError("%s has length %d, expected %d" % (name, v.shape[0], n))
+    return v
+
+
+class IpmSolver:
+    """One LP bound to one GPU: owns a libipm_hip handle whose workspace is a torch tensor."""
+
+    def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
+                 check_every=4, use_torch=True):
+        lib = _lib.load()
+        self._lib = lib
+        self._h = None
+        if _sp is not None and _sp.issparse(A):
+            A = _sp.csc_matrix(A, dtype=np.float64)
+            A.sum_duplicates()
+            m, n = A.shape
+        else:
+            A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+            if A.ndim != 2:
+                raise ValueError("A must be 2-D")
+            m, n = A.shape
+        self.m, self.n = int(m), int(n)
+        b = _col(b, self.m, "b")
+        c = _col(c, self.n, "c")
+        opts = _lib.Options()
+        lib.ipm_default_options(C.byref(opts))
+        opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
+        opts.check_every = int(check_every)
+        nbytes = C.c_size_t(0)
+        _lib.check(None, lib.ipm_workspace_bytes(self.m, self.n, C.byref(nbytes)))
+        self.workspace_bytes = nbytes.value
+        ws_ptr, stream = None, None
+        self._ws = None
+        if use_torch:
+            import torch
+            if not torch.cuda.is_available():
+                raise _lib.IpmLibraryError("no ROCm device visible to torch; the HIP path cannot run")
+            dev = torch.device("cuda", device)
+            self._ws = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=dev)   # device buffer only
+            ws_ptr = C.c_void_p(self._ws.data_ptr())
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        h = C.c_void_p()
+        _lib.check(None, lib.ipm_create(int(device), self.m, self.n, C.byref(opts), ws_ptr,
+                                        self.workspace_bytes if ws_ptr else 0, stream, C.byref(h)))
+        self._h = h
+        if _sp is not None and _sp.issparse(A):
+            indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+            indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+            data = np.ascontiguousarray(A.data, dtype=np.float64)
+            self._check(lib.ipm_set_A_csc(h, indptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          indices.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(data),
+                                          int(data.shape[0])))
+        else:
+            self._check(lib.ipm_set_A_dense(h, C.c_void_p(A.ctypes.data), self.n, 0))
+        self._check(lib.ipm_set_bc(h, _dptr(b), _dptr(c)))
+        self.stats = None
+
+    # -- plumbing
+    def _check(self, code):
+        _lib.check(self._h, code)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.ipm_destroy(self._h)
+            self._h = None
+            self._ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state
+    def init_state(self, y0=1.0):
+        self._check(self._lib.ipm_init_state(self._h, float(y0)))
+
+    def set_state(self, x, y, s):
+        x, y, s = _col(x, self.n, "x"), _col(y, self.m, "y"), _col(s, self.n, "s")
+        self._check(self._lib.ipm_set_state(self._h, _dptr(x), _dptr(y), _dptr(s)))
+
+    def get_state(self):
+        x, y, s = np.empty(self.n), np.empty(self.m), np.empty(self.n)
+        self._check(self._lib.ipm_get_state(self._h, _dptr(x), _dptr(y), _dptr(s)))
+        return x.reshape(-1, 1), y.reshape(-1, 1), s.reshape(-1, 1)
+
+    # -- seams
+    def newton_direction(self, corrector=False):
+        dx, dy, ds = np.empty(self.n), np.empty(self.m), np.empty(self.n)
+        st = _lib.Stats()
+        self._check(self._lib.ipm_newton_direction(self._h, 1 if corrector else 0, _dptr(dx), _dptr(dy),
+                                                   _dptr(ds), C.byref(st)))
+        self.stats = st.as_dict()
+        return dx.reshape(-1, 1), dy.reshape(-1, 1), ds.reshape(-1, 1)
+
+    def iterate(self, n_steps):
+        st = _lib.Stats()
+        self._check(self._lib.ipm_iterate(self._h, int(n_steps), C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def solve(self, tol=1e-8, max_iter=5000, tol_gap=None):
+        st = _lib.Stats()
+        e3 = tol if tol_gap is None else tol_gap
+        self._check(self._lib.ipm_solve(self._h, float(tol), float(tol), float(e3), int(max_iter), C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def set_profiling(self, on=True):
+        self._check(self._lib.ipm_set_profiling(self._h, 1 if on else 0))
+
+    def phase_ms(self):
+        out = (C.c_double * 4)()
+        self._check(self._lib.ipm_get_phase_ms(self._h, out))
+        return dict(form=out[0], factor=out[1], trisolve=out[2], other=out[3])
+
+    # -- kernel-level
+    def form_normal_matrix(self, d):
+        d = _col(d, self.n, "d")
+        B = np.empty((self.m, self.m))
+        self._check(self._lib.ipm_form_normal_matrix(self._h, _dptr(d), _dptr(B), self.m))
+        return B
+
+    def get_factor(self):
+        L = np.empty((self.m, self.m))
+        self._check(self._lib.ipm_get_factor(self._h, _dptr(L), self.m))
+        return L
+
+    def solve_linear(self, B, rhs):
+        B = np.ascontiguousarray(np.asarray(B, dtype=np.float64))
+        rhs = _col(rhs, self.m, "rhs")
+        z = np.empty(self.m)
+        nfix = C.c_int32(0)
+        self._check(self._lib.ipm_solve_linear(self._h, _dptr(B), self.m, _dptr(rhs), _dptr(z), C.byref(nfix)))
+        return z.reshape(-1, 1), nfix.value
+
+
+def _info(solver, cTlb=0.0):
+    st = dict(solver.stats)
+    st["status_name"] = STATUS_NAMES.get(st["status"], "?")
+    st["rp"] = st["rp_norm"] / (1.0 + st["b_norm"])          # reference scaling, main.py:170
+    st["rd"] = st["rd_norm"] / (1.0 + st["c_norm"])          # main.py:171
+    st["objective_minus_cTlb"] = st["objective"] - cTlb
+    return st
+
+
+_last_info = None
+
+
+def last_info():
+    """Statistics of the most recent solve()/interior*() call in this process."""
+    return _last_info
+
+
+def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=None, **opts):
+    """solve() plus the statistics record (iterations, status, objective, rp, rd, gap, ...)."""
+    global _last_info
+    with IpmSolver(A, b, c, device=device, **opts) as sv:
+        sv.init_state(y0)
+        sv.solve(tol=tol, max_iter=max_iter, tol_gap=tol_gap)
+        x, y, s = sv.get_state()
+        info = _info(sv)
+    _last_info = info
+    return x, y, s, info
+
+
+def solve(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, **opts):
+    """min c^T x s.t. Ax=b, x>=0 by the Mehrotra predictor-corrector loop on the GPU -> (x, y, s)."""
+    x, y, s, _ = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device, **opts)
+    return x, y, s
+
+
+def interior_sparse(A, b, c, cTlb=0.0, tol=1e-20, device=0):
+    """Drop-in for main.py:760-815: start x=s=y=1, cap 5000, returns sum(x*c) - cTlb."""
+    _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=5000, y0=1.0, device=device)
+    return info["objective"] - float(cTlb)
+
+
+def interior(A, b, c, tol=1e-20, device=0):
+    """Drop-in for main.py:707-757 (dense path: y0=0, cap 50000); returns the objective."""
+    _, _, _, info = solve_with_info(np.asarray(A, dtype=np.float64), b, c, tol=tol, max_iter=50000, y0=0.0,
+                                    device=device)
+    return info["objective"]
+
+
+def direction_predicted_sparse(A, b, c, x, y, s, method="normal", device=0):
+    """main.py:197: predictor direction at (x, y, s).  Only method="normal" exists on the GPU."""
+    if method != "normal":
+        raise ValueError('the HIP path implements method="normal" (main.py:221-229) only')
+    with IpmSolver(A, b, c, device=device) as sv:
+        sv.set_state(x, y, s)
+        return sv.newton_direction(corrector=False)
+
+
+def direction_corrected_sparse(A, b, c, x, y, s, delta_x_aff=None, delta_y_aff=None, delta_s_aff=None,
+                               method="normal", device=0):
+    """main.py:247: corrector direction.  The affine direction is recomputed on the device from
+    (x, y, s) (same factor reused), so the delta_*_aff arguments are accepted for signature
+    compatibility only."""
+    with IpmSolver(A, b, c, device=device) as sv:
+        sv.set_state(x, y, s)
+        sv.newton_direction(corrector=False)
+        return sv.newton_direction(corrector=True)
+
+
+def solve_linear(A, b, method="hip", device=0):
+    """main.py:176-182 for a symmetric positive (semi)definite matrix: guarded Cholesky on the GPU."""
+    B = np.asarray(A.todense() if (_sp is not None and _sp.issparse(A)) else A, dtype=np.float64)
+    m = B.shape[0]
+    rhs = np.asarray(b, dtype=np.float64).reshape(-1)
+    with IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1), device=device) as sv:
+        z, _ = sv.solve_linear(B, rhs)
+    return z

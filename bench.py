@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- IPM iterations/sec of the HIP Newton/KKT path on the dense synthetic LP.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full Mehrotra predictor-corrector iteration (stop
+test, form A D^2 A^T, Cholesky, two solves, two ratio tests, update) on the BASELINE.json
+config "dense synthetic LP m=4096 n=8192 fp64" (generator of SURVEY.md 8d, seed 0, start
+x=s=1, y=0).  All inputs are resident in HBM before the timed region.  The iterate is reset
+to the start point every 20 steps (3 tiny fill launches, inside the timed region) so that
+any K stays on the pre-convergence trajectory (the LP converges in 24 iterations).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the single-LP dense path does
+not shard ("replicas only"): every rank solves its own replica, no data-path
+collective; value = N*K / max-over-ranks time  (weak scaling).
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (the dominant kernel,
+the fp64-MFMA A D^2 A^T contraction, timed with HIP events on the solver's stream inside the
+timed region) and `cpu_baseline` (the NumPy normal-equations oracle on the host cores,
+bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M_DEFAULT, N_DEFAULT = 4096, 8192
+RESET_EVERY = 20
+PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense fp64 matrix peak
+
+
+def cpu_baseline(A, b, c, budget_s=20.0, max_its=6):
+    """Oracle (NumPy normal equations + LAPACK Cholesky) timed on the host: bounded sample."""
+    import numpy as np
+    from oracle import ipm_oracle as O
+    m, n = A.shape
+    x, y, s = O.initial_point(m, n, 0.0)
+    t0 = time.perf_counter()
+    its = 0
+    while its < max_its and (time.perf_counter() - t0) < budget_s:
+        x, y, s, _ = O.iterate(A, b, c, x, y, s, method="normal")
+        its += 1
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": its / dt, "unit": "iterations/s", "cores": int(threads), "kind": "port",
+            "sample": "%d iterations of oracle.iterate(method='normal') (NumPy (A*d)@A.T + LAPACK potrf) "
+                      "on the same %dx%d LP from the start point, %.1f s, host has %d logical CPUs" % (
+                          its, m, n, dt, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--m", type=int, default=M_DEFAULT)
+    ap.add_argument("--n", type=int, default=N_DEFAULT)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import interiorpointmethod_amd as ipm
+    from interiorpointmethod_amd.workloads import synthetic_lp, flops_per_iteration
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ngpu = max(world, 1)
+    if args.gpus != ngpu and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    m, n = args.m, args.n
+    A, b, c = synthetic_lp(m, n, seed=0)              # same LP on every rank (replicas)
+    sv = ipm.IpmSolver(A, b, c, device=local_rank)
+
+    def run(steps, profile=False):
+        sv.set_profiling(profile)
+        done, total_ms = 0, 0.0
+        form_ms = factor_ms = tri_ms = other_ms = 0.0
+        while done < steps:
+            k = min(RESET_EVERY, steps - done)
+            sv.init_state(0.0)
+            st = sv.iterate(k)
+            total_ms += st["solve_ms"]
+            if profile:
+                ph = sv.phase_ms()
+                form_ms += ph["form"] * k; factor_ms += ph["factor"] * k
+                tri_ms += ph["trisolve"] * k; other_ms += ph["other"] * k
+            done += k
+        return total_ms, (form_ms, factor_ms, tri_ms, other_ms), st
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    dev_ms, phases, st = run(args.steps, profile=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        K = args.steps
+        its_per_s = ngpu * K / elapsed
+        form_ms = phases[0] / K
+        flops_form = float(m) * m * n                       # lower-triangle SYRK, SURVEY 8(d)
+        achieved = flops_form / (form_ms * 1e-3) / 1e12 if form_ms > 0 else 0.0
+        out = {
+            "metric": "IPM iterations/sec (m=%d,n=%d dense LP)" % (m, n),
+            "value": its_per_s, "unit": "iterations/s", "n_gpus": ngpu, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "dense synthetic LP m=%d n=%d fp64, seed 0, start x=s=1 y=0 "
+                                   "(BASELINE.json configs[1]); replicas per GPU" % (m, n),
+                       "reset_every": RESET_EVERY},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "gemm_nt_f64_kernel<128,128,16,2,2> (B = A diag(d) A^T)",
+                         "flops_per_launch": flops_form, "avg_launch_ms": form_ms},
+            "phases_ms_per_step": {"form": form_ms, "factor": phases[1] / K, "trisolve": phases[2] / K,
+                                   "other": phases[3] / K, "device_total": dev_ms / K},
+            "whole_iteration": {"flops_per_iteration": flops_per_iteration(m, n),
+                                "tflops": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12,
+                                "frac_of_fp64_mfma_peak": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12 / PEAK_FP64_MFMA_TFLOPS},
+            "objective_after_last_block": st["objective"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, b, c)
+        print(json.dumps(out))
+    sv.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64/libhsa-runtime64 and preloads them by path.  Two HSA
+    # runtimes cannot share one process (the second sees no device), so when torch is
+    # installed it is imported FIRST: libipm_hip.so's NEEDED libamdhip64.so.7 then resolves to
+    # the copy torch already mapped.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     if not os.path.exists(LIB_PATH):
         raise IpmLibraryError(
             "%s not found: the HIP extension has not been built. Build it with "

@@ -371,7 +371,8 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 // blocked guarded Cholesky of B in place (lower)
 static int enqueue_factor(ipm_handle* h) {
     const int* done = &h->sc->done;
-    hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->mp, &h->sc->maxdiag, done);
+    // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
+    hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     for (int k = 0; k < h->nblk; ++k) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;

@@ -1,0 +1,258 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against NumPy, the oracle
+and the golden vectors generated from the reference.  fp64 throughout; the north-star
+tolerance is 1e-6 relative on objective and scaled residuals, kernel-level
+comparisons use much tighter bounds written next to each assert."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+import interiorpointmethod_amd as ipm                      # noqa: E402
+from interiorpointmethod_amd.matio import load_npz_problem  # noqa: E402
+from interiorpointmethod_amd.workloads import synthetic_lp  # noqa: E402
+from oracle import ipm_oracle as O                          # noqa: E402
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+# ------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("m,n", [(1, 1), (16, 32), (127, 65), (128, 64), (129, 1000), (200, 300), (1000, 2000)])
+def test_form_normal_matrix(m, n):
+    rng = np.random.default_rng(m * 7 + n)
+    A = rng.standard_normal((m, n))
+    d = rng.uniform(1e-3, 1e3, n)
+    with ipm.IpmSolver(A, np.zeros(m), np.zeros(n)) as sv:
+        B = sv.form_normal_matrix(d)
+    ref = (A * d) @ A.T
+    assert rel(B, ref) < 1e-13
+    assert np.array_equal(B, B.T)
+
+
+def test_form_exact_integers_asymmetric():
+    """Exact small-integer data: any wrong MFMA lane map or tile offset shows as a nonzero diff."""
+    m, n = 150, 70
+    A = (np.arange(m * n).reshape(m, n) * 7 % 11 - 5).astype(np.float64)
+    A[3, 5] = 13.0
+    d = (np.arange(n) % 5 + 1).astype(np.float64)
+    with ipm.IpmSolver(A, np.zeros(m), np.zeros(n)) as sv:
+        B = sv.form_normal_matrix(d)
+    assert np.array_equal(B, (A * d) @ A.T)
+
+
+def test_form_wide_dynamic_range():
+    """d spans > 50 decades on the reference's trajectories."""
+    rng = np.random.default_rng(5)
+    m, n = 90, 400
+    A = rng.standard_normal((m, n))
+    d = 10.0 ** rng.uniform(-40, 15, n)
+    with ipm.IpmSolver(A, np.zeros(m), np.zeros(n)) as sv:
+        B = sv.form_normal_matrix(d)
+    ref = (A * d) @ A.T
+    assert rel(B, ref) < 1e-12
+
+
+@pytest.mark.parametrize("m", [1, 16, 100, 128, 129, 300, 700, 1500])
+def test_cholesky_and_solve(m):
+    rng = np.random.default_rng(m)
+    M = rng.standard_normal((m, m + 10))
+    B = M @ M.T + 0.1 * np.eye(m)
+    rhs = rng.standard_normal(m)
+    with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+        z, nfix = sv.solve_linear(B, rhs)
+        L = sv.get_factor()
+    assert nfix == 0
+    assert rel(L, np.linalg.cholesky(B)) < 1e-11
+    assert np.linalg.norm(B @ z.ravel() - rhs) / np.linalg.norm(rhs) < 1e-10
+
+
+def test_solve_linear_is_linear_and_deterministic():
+    rng = np.random.default_rng(11)
+    m = 400
+    M = rng.standard_normal((m, m))
+    B = M @ M.T + np.eye(m)
+    r1, r2 = rng.standard_normal(m), rng.standard_normal(m)
+    with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+        z1, _ = sv.solve_linear(B, r1)
+        z2, _ = sv.solve_linear(B, r2)
+        z12, _ = sv.solve_linear(B, 2.0 * r1 - 3.0 * r2)
+        z1b, _ = sv.solve_linear(B, r1)
+    assert rel(z12, 2.0 * z1 - 3.0 * z2) < 1e-10
+    assert np.array_equal(z1, z1b)                       # fixed-order reductions: bitwise reproducible
+
+
+def test_pivot_guard_rank_deficient():
+    """rank-deficient normal matrices must not produce NaN; the guard reports its fixes."""
+    rng = np.random.default_rng(7)
+    m = 200
+    M = rng.standard_normal((m, 150))
+    B = M @ M.T
+    rhs = B @ rng.standard_normal(m)
+    with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+        z, nfix = sv.solve_linear(B, rhs)
+    assert 40 <= nfix <= 60 and np.all(np.isfinite(z))
+    assert np.linalg.norm(B @ z.ravel() - rhs) / np.linalg.norm(rhs) < 1e-6
+    Lo, fo = O.guarded_cholesky(B)
+    assert abs(fo - nfix) <= 5
+
+
+def test_tiny_normal_matrix_is_not_guarded():
+    """max diag(B) over the true rows sets the guard scale: a uniformly tiny B (d ~ 1e-41 on the
+    AFIRO trajectory) must factor without a single fix."""
+    rng = np.random.default_rng(2)
+    m = 27
+    M = rng.standard_normal((m, 60))
+    B = (M @ M.T) * 1e-41
+    rhs = rng.standard_normal(m)
+    with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+        z, nfix = sv.solve_linear(B, rhs)
+    assert nfix == 0
+    assert np.linalg.norm(B @ z.ravel() - rhs) / np.linalg.norm(rhs) < 1e-9
+
+
+# ------------------------------------------------------------------ direction seam vs the reference
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "BANDM"])
+def test_direction_kats(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "kat_%s.npz" % name))
+    m, n = (int(v) for v in z["shape"])
+    A = sparse.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=(m, n))
+    with ipm.IpmSolver(A, z["b"], z["c"]) as sv:
+        k = 0                                            # start point: well conditioned, tight bound
+        pre = "k0_"
+        sv.set_state(z[pre + "x"], z[pre + "y"], z[pre + "s"])
+        dxa, dya, dsa = sv.newton_direction(False)
+        st = dict(sv.stats)
+        assert rel(dxa, z[pre + "dxa"]) < 1e-11 and rel(dya, z[pre + "dya"]) < 1e-11 and rel(dsa, z[pre + "dsa"]) < 1e-11
+        assert rel(dxa, z[pre + "normal_dxa"]) < 1e-11          # reference method="normal", main.py:221-229
+        assert np.isclose(st["alpha_aff_p"], float(z[pre + "alpha_aff_p"]), rtol=1e-10)
+        assert np.isclose(st["alpha_aff_d"], float(z[pre + "alpha_aff_d"]), rtol=1e-10)
+        dx, dy, ds = sv.newton_direction(True)
+        assert np.isclose(sv.stats["sigma"], float(z[pre + "sigma"]), rtol=1e-9)
+        assert np.isclose(sv.stats["mu"], float(z[pre + "mu"]), rtol=1e-12)
+        assert rel(dx, z[pre + "dx"]) < 1e-10 and rel(dy, z[pre + "dy"]) < 1e-10 and rel(ds, z[pre + "ds"]) < 1e-10
+        # one full iteration reproduces the reference's next iterate
+        sv.set_state(z[pre + "x"], z[pre + "y"], z[pre + "s"])
+        st = sv.iterate(1)
+        xn, yn, sn = sv.get_state()
+        assert np.isclose(st["alpha_p"], float(z[pre + "alpha_p"]), rtol=1e-9)
+        assert np.isclose(st["alpha_d"], float(z[pre + "alpha_d"]), rtol=1e-9)
+        assert rel(xn, z[pre + "xn"]) < 1e-10 and rel(yn, z[pre + "yn"]) < 1e-10 and rel(sn, z[pre + "sn"]) < 1e-10
+        # a later iterate (ill-conditioned: dy/ds still agree with the full-KKT reference)
+        k = int(z["iters"][1])
+        pre = "k%d_" % k
+        sv.set_state(z[pre + "x"], z[pre + "y"], z[pre + "s"])
+        dxa, dya, dsa = sv.newton_direction(False)
+        assert rel(dya, z[pre + "dya"]) < 1e-8 and rel(dsa, z[pre + "dsa"]) < 1e-8
+
+
+def test_qap15_direction_kat(golden_dir):
+    """Config 3 (QAP15, 6330 x 22275, rank-deficient): predictor direction at the start point vs the
+    reference's method="normal" (18 s of SuperLU there).  A is rank deficient, so dy is not unique;
+    A^T dy, dx and ds are, and those are compared."""
+    z = np.load(os.path.join(golden_dir, "kat_QAP15_normal_k0.npz"))
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "QAP15.npz"))
+    m, n = A.shape
+    with ipm.IpmSolver(A, b, c) as sv:
+        sv.init_state(1.0)
+        dxa, dya, dsa = sv.newton_direction(False)
+        st = dict(sv.stats)
+    assert rel(dxa, z["dxa"]) < 1e-6 and rel(dsa, z["dsa"]) < 1e-6
+    assert np.isclose(st["alpha_aff_p"], float(z["alpha_aff_p"]), rtol=1e-6)
+    assert np.isclose(st["alpha_aff_d"], float(z["alpha_aff_d"]), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ solver seam vs the reference
+@pytest.mark.parametrize("nm", ["ex1", "ex2", "ex3", "syn_64x128", "syn_256x512", "syn_512x1024"])
+def test_dense_end_to_end(golden_dir, nm):
+    z = np.load(os.path.join(golden_dir, "dense_%s.npz" % nm))
+    if nm.startswith("syn"):
+        m, n = (int(v) for v in z["shape"])
+        A, b, c = synthetic_lp(m, n)
+    else:
+        A, b, c = z["A"], z["b"], z["c"]
+    x, y, s, info = ipm.solve_with_info(A, b, c, tol=1e-8, y0=0.0, max_iter=50000)
+    ref = float(z["objective"])
+    assert info["status_name"] == "converged"
+    assert abs(info["objective"] - ref) <= 1e-6 * max(1.0, abs(ref))
+    assert info["rp"] <= 1e-6 and info["rd"] <= 1e-6 and info["gap"] <= 1e-8
+    assert abs(info["iterations"] - int(z["iterations"])) <= 2
+    assert rel(x, z["x"]) < 1e-5
+    assert x.shape == (A.shape[1], 1) and y.shape == (A.shape[0], 1) and s.shape == x.shape
+
+
+PARITY_FAST = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "GROW7", "KB2", "SC105", "SC205",
+               "SC50A", "SC50B", "SCSD1", "SCSD6", "SCSD8", "SCTAP1", "SCTAP2", "SCTAP3", "SHARE2B", "STOCFOR1",
+               "STOCFOR2", "TRUSS", "WOODW", "MAROS-R7"]
+
+
+@pytest.mark.parametrize("name", PARITY_FAST)
+def test_netlib_parity(golden_dir, name):
+    """Parity set of BASELINE.md 2.4 (the files on which the verbatim reference loop converges)."""
+    e = np.load(os.path.join(golden_dir, "e2e_%s.npz" % name))
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    x, y, s, info = ipm.solve_with_info(A, b, c, tol=1e-8, y0=1.0, max_iter=5000)
+    ref = float(e["objective"])
+    assert info["status_name"] == "converged", info
+    assert abs(info["objective"] - ref) <= 1e-6 * max(1.0, abs(ref))
+    assert info["rp"] <= 1e-6 and info["rd"] <= 1e-6 and info["gap"] <= 1e-8
+    if name != "DEGEN2":      # guarded Cholesky legitimately converges in ~24 instead of 223
+        assert abs(info["iterations"] - int(e["iterations"])) <= 2
+    # the returned iterate satisfies the reference's own stop test on the host
+    assert not O.check_optimality(*O.as_float64_problem(A, b, c), x, y, s, 1e-8, 1e-8, 1e-8)
+
+
+def test_interior_sparse_drop_in(golden_dir):
+    """interior_sparse(A, b, c, cTlb, tol) returns sum(x*c) - cTlb like main.py:815."""
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "AFIRO.npz"))
+    obj = ipm.interior_sparse(A, b, c, cTlb, tol=1e-8)
+    assert abs(obj - (-464.7531428559395)) < 1e-6 * 464.75
+    assert abs(obj - (-4.6475314286e2)) < 1e-5            # Netlib optimum, benchmarks/readme.txt:88
+    assert ipm.last_info()["iterations"] in (92, 93, 94, 95)
+
+
+def test_integer_dtype_inputs(golden_dir):
+    """the .mat files hold int16/uint8 arrays; the boundary casts to float64."""
+    A, b, c = np.array([[3, 6, 8], [8, 4, 1]], dtype=np.int16), np.array([30, 44], dtype=np.uint8), \
+        np.array([-100, -125, -20], dtype=np.int16)
+    x, y, s = ipm.solve(A, b, c, tol=1e-8, y0=0.0)
+    assert abs(float(c @ x.ravel()) + 775) < 1e-5           # ex1 optimum, main.py:1253
+
+
+def test_invalid_inputs_rejected(golden_dir):
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "CAPRI.npz"))
+    assert not valid
+    with pytest.raises(ipm.IpmError) as ei:
+        ipm.solve(A, b, c)
+    assert ei.value.code == -6
+
+
+# ------------------------------------------------------------------ BASELINE.json full size
+def test_dense_4096x8192_full_solve():
+    """configs[1]: converges in 24 iterations to the value pinned in BASELINE.md 2.2."""
+    A, b, c = synthetic_lp(4096, 8192)
+    with ipm.IpmSolver(A, b, c) as sv:
+        sv.init_state(0.0)
+        st = sv.solve(tol=1e-8, max_iter=200)
+        x, y, s = sv.get_state()
+        sv.init_state(0.0)
+        st2 = sv.solve(tol=1e-8, max_iter=200)
+        x2, _, _ = sv.get_state()
+    assert st["status"] == 1 and abs(st["iterations"] - 24) <= 2
+    assert abs(st["objective"] - (-3.761254474176e+02)) <= 1e-6 * 3.77e2
+    # size-independent properties: feasibility, complementarity, weak duality gap closes
+    rb = A @ x - b
+    rc = A.T @ y + s - c
+    assert np.linalg.norm(rb) / (1 + np.linalg.norm(b)) < 1e-8
+    assert np.linalg.norm(rc) / (1 + np.linalg.norm(c)) < 1e-8
+    assert np.all(x > 0) and np.all(s > 0) and float(x.T @ s) <= 1e-8
+    assert abs(float(c.T @ x) - float(b.T @ y)) <= 1e-6 * 3.77e2
+    assert np.array_equal(x, x2) and st2["iterations"] == st["iterations"]     # bitwise reproducible
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

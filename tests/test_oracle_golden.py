@@ -1,0 +1,141 @@
+"""The CPU oracle (oracle/ipm_oracle.py) against golden vectors generated from the reference
+(tests/golden/make_golden.py imports main.py / sparse_interior.py in the build container).
+
+Trajectories of the reference are chaotic, so single-step quantities are compared
+tightly at the recorded iterates and end-to-end runs on objective / iteration count.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import ipm_oracle as O
+from interiorpointmethod_amd.matio import load_npz_problem
+from interiorpointmethod_amd.workloads import synthetic_lp
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+def _kat(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "kat_%s.npz" % name))
+    m, n = (int(v) for v in z["shape"])
+    A = sparse.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=(m, n))
+    return z, A, z["b"], z["c"]
+
+
+def test_afiro_start_point_pins(golden_dir):
+    """Numbers recorded in SURVEY.md 8c from the reference at the AFIRO start point."""
+    z, A, b, c = _kat(golden_dir, "AFIRO")
+    assert np.isclose(np.linalg.norm(z["k0_dxa"]), 567.731603582373, rtol=1e-12)
+    assert np.isclose(np.linalg.norm(z["k0_dya"]), 439.3339911194103, rtol=1e-12)
+    assert np.isclose(float(z["k0_sigma"]), 0.9491541210153083, rtol=1e-12)
+    assert np.isclose(float(z["k0_alpha_p"]), 8.487299511995689e-05, rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "BANDM"])
+def test_direction_kats(golden_dir, name):
+    z, A, b, c = _kat(golden_dir, name)
+    for k in z["iters"]:
+        pre = "k%d_" % int(k)
+        x, y, s = z[pre + "x"], z[pre + "y"], z[pre + "s"]
+        early = int(k) == 0
+        rc, rb, r3 = O.residuals(A, b, c, x, y, s)
+        # full-KKT restatement == reference full-KKT direction
+        dxf, dyf, dsf = O.direction_full(A, rc, rb, r3, x, s)
+        tol = 1e-9 if early else 1e-5
+        assert rel(dyf, z[pre + "dya"]) < tol and rel(dsf, z[pre + "dsa"]) < tol
+        # normal-equations restatement == reference method="normal" (main.py:221-229)
+        dxn, dyn, dsn, L, fixed = O.direction_normal(A, rc, rb, r3, x, s)
+        assert rel(dyn, z[pre + "normal_dya"]) < (1e-9 if early else 1e-4)
+        if early:
+            assert rel(dxn, z[pre + "dxa"]) < 1e-9 and rel(dxn, z[pre + "normal_dxa"]) < 1e-9
+        # step lengths / centering from the reference's affine direction
+        ap, ad = O.predicted_stepsize(z[pre + "dxa"], z[pre + "dsa"], x, s)
+        assert np.isclose(ap, float(z[pre + "alpha_aff_p"]), rtol=1e-12)
+        assert np.isclose(ad, float(z[pre + "alpha_aff_d"]), rtol=1e-12)
+        mu_aff, mu, sigma = O.centering(x, s, z[pre + "dxa"], z[pre + "dsa"])
+        assert np.isclose(mu, float(z[pre + "mu"]), rtol=1e-12)
+        assert np.isclose(sigma, float(z[pre + "sigma"]), rtol=1e-9)
+        fp, fd = O.full_stepsize(z[pre + "dx"], z[pre + "ds"], x, s)
+        assert np.isclose(fp, float(z[pre + "alpha_p"]), rtol=1e-12)
+        assert np.isclose(fd, float(z[pre + "alpha_d"]), rtol=1e-12)
+        assert O.check_optimality(A, b, c, x, y, s, 1e-8, 1e-8, 1e-8) == bool(z[pre + "continue"])
+        if early:
+            xn, yn, sn, info = O.iterate(A, b, c, x, y, s, method="normal")
+            assert rel(xn, z[pre + "xn"]) < 1e-9 and rel(sn, z[pre + "sn"]) < 1e-9 and rel(yn, z[pre + "yn"]) < 1e-9
+
+
+@pytest.mark.parametrize("nm", ["ex1", "ex2", "ex3", "syn_64x128", "syn_256x512"])
+@pytest.mark.parametrize("method", ["full", "normal"])
+def test_dense_end_to_end(golden_dir, nm, method):
+    z = np.load(os.path.join(golden_dir, "dense_%s.npz" % nm))
+    if nm.startswith("syn"):
+        m, n = (int(v) for v in z["shape"])
+        A, b, c = synthetic_lp(m, n)
+        assert A[0, 0] == 0.1257302210933933 and np.array_equal(b, z["b"]) and np.array_equal(c, z["c"])
+    else:
+        A, b, c = z["A"], z["b"], z["c"]
+    x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=0.0, method=method, max_iter=50000)
+    ref = float(z["objective"])
+    assert abs(info["objective"] - ref) <= 1e-9 * max(1.0, abs(ref))
+    assert info["iterations"] == int(z["iterations"])
+    if method == "full":
+        assert rel(x, z["x"]) < 1e-6
+    if nm == "ex1":
+        assert abs(info["objective"] + 775) < 1e-6          # main.py:1253
+    if nm == "ex2":
+        assert abs(info["objective"] + 15000) < 1e-5        # main.py:1261
+
+
+E2E_SMALL = ["AFIRO", "SC50A", "SC50B", "SC105", "SC205", "KB2", "SHARE2B", "STOCFOR1", "E226", "BANDM", "SCSD1"]
+
+
+@pytest.mark.parametrize("name", E2E_SMALL)
+def test_netlib_end_to_end_normal(golden_dir, name):
+    """Normal equations + guarded Cholesky reach the reference's objective (parity criterion 8d)."""
+    e = np.load(os.path.join(golden_dir, "e2e_%s.npz" % name))
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    assert valid
+    x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=1.0, method="normal", max_iter=500)
+    ref = float(e["objective"])
+    assert info["status"] == O.STATUS_OK
+    assert abs(info["objective"] - ref) <= 1e-6 * max(1.0, abs(ref))
+    assert info["rp"] <= 1e-6 and info["rd"] <= 1e-6 and info["gap"] <= 1e-8
+    assert abs(info["iterations"] - int(e["iterations"])) <= 2
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC50A", "KB2"])
+def test_netlib_end_to_end_full(golden_dir, name):
+    """The full-KKT restatement follows the reference loop exactly (same count, same iterate)."""
+    e = np.load(os.path.join(golden_dir, "e2e_%s.npz" % name))
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=1.0, method="full", max_iter=500)
+    assert info["iterations"] == int(e["iterations"])
+    assert abs(info["objective"] - float(e["objective"])) <= 1e-9 * max(1.0, abs(float(e["objective"])))
+
+
+def test_afiro_netlib_optimum(golden_dir):
+    e = np.load(os.path.join(golden_dir, "e2e_AFIRO.npz"))
+    assert abs(float(e["objective"]) - (-4.6475314286e2)) < 1e-6       # benchmarks/readme.txt:88
+    assert int(e["iterations"]) == 93
+
+
+def test_guarded_cholesky_rank_deficient():
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((60, 40))
+    B = M @ M.T
+    L, fixed = O.guarded_cholesky(B)
+    assert fixed >= 15 and np.all(np.isfinite(L))
+    rhs = B @ rng.standard_normal((60, 1))
+    z = O.cholesky_solve(L, rhs)
+    assert np.linalg.norm(B @ z - rhs) / np.linalg.norm(rhs) < 1e-6
+
+
+def test_invalid_netlib_inputs_flagged(golden_dir):
+    bad = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(golden_dir, "netlib", "*.npz"))
+                 if not bool(np.load(f)["valid"]))
+    assert bad == ["CAPRI", "CYCLE", "GREENBEB", "MODSZK1", "PEROLD", "PILOT4", "STAIR", "TUFF"]

@@ -53,7 +53,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SCALE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
 void gemm_nt_f64_kernel(GemmNT g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -102,34 +102,32 @@ void gemm_nt_f64_kernel(GemmNT g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-    f64x2 pr[PL], qr[QL];
+    // All global loads of a stage are issued back to back (no use before store_stage), so they
+    // stay in flight under the MFMA block of the previous stage.  The k-scaling is applied when
+    // the Q tile is written to LDS.  NT % CH == 0, so a thread's chunk column ch is the same for
+    // every i: one w load per thread per stage.
+    static_assert(NT % CH == 0, "chunk column must be loop invariant");
+    f64x2 pr[PL], qr[QL], wr;
+    const int ch0 = tid % CH, r0t = tid / CH;
+    constexpr int RSTEP = NT / CH;
     auto load_stage = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < PL; ++i) {
-            int c = tid + i * NT, r = c / CH, ch = c % CH;
-            pr[i] = *reinterpret_cast<const f64x2*>(Pg + (int64_t)r * g.ldp + k0 + ch * 2);
-        }
+        for (int i = 0; i < PL; ++i)
+            pr[i] = *reinterpret_cast<const f64x2*>(Pg + (int64_t)(r0t + i * RSTEP) * g.ldp + k0 + ch0 * 2);
 #pragma unroll
-        for (int i = 0; i < QL; ++i) {
-            int c = tid + i * NT, r = c / CH, ch = c % CH;
-            f64x2 v = *reinterpret_cast<const f64x2*>(Qg + (int64_t)r * g.ldq + k0 + ch * 2);
-            if (g.w) {
-                f64x2 ww = *reinterpret_cast<const f64x2*>(g.w + k0 + ch * 2);
-                v.x *= ww.x; v.y *= ww.y;
-            }
-            qr[i] = v;
-        }
+        for (int i = 0; i < QL; ++i)
+            qr[i] = *reinterpret_cast<const f64x2*>(Qg + (int64_t)(r0t + i * RSTEP) * g.ldq + k0 + ch0 * 2);
+        if (SCALE) wr = *reinterpret_cast<const f64x2*>(g.w + k0 + ch0 * 2);
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < PL; ++i) {
-            int c = tid + i * NT, r = c / CH, ch = c % CH;
-            *reinterpret_cast<f64x2*>(Ps + (buf * BM + r) * LDT + ch * 2) = pr[i];
-        }
+        for (int i = 0; i < PL; ++i)
+            *reinterpret_cast<f64x2*>(Ps + (buf * BM + r0t + i * RSTEP) * LDT + ch0 * 2) = pr[i];
 #pragma unroll
         for (int i = 0; i < QL; ++i) {
-            int c = tid + i * NT, r = c / CH, ch = c % CH;
-            *reinterpret_cast<f64x2*>(Qs + (buf * BN + r) * LDT + ch * 2) = qr[i];
+            f64x2 v = qr[i];
+            if (SCALE) { v.x *= wr.x; v.y *= wr.y; }
+            *reinterpret_cast<f64x2*>(Qs + (buf * BN + r0t + i * RSTEP) * LDT + ch0 * 2) = v;
         }
     };
 
@@ -161,7 +159,29 @@ void gemm_nt_f64_kernel(GemmNT g) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row=(l>>4)+4q][col=l&15]
+    // ---- epilogue: D[row=(l>>4)+4q][col=l&15].  beta is 0 or 1 on this path; for beta != 0 all
+    // C loads are issued before the first use so they overlap (a load-use-store chain per
+    // element costs an L2 round trip each: 64 serialized round trips per thread).
+    double* cbase = g.C + (int64_t)(row0 + wm * WTM + fk) * g.ldc + col0 + wn * WTN + fr;
+    if (g.beta != 0.0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            double cold[NI][4];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cold[j][q] = cbase[(int64_t)(i * 16 + 4 * q) * g.ldc + j * 16];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][j][q] = g.alpha * acc[i][j][q] + g.beta * cold[j][q];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] *= g.alpha;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -170,11 +190,9 @@ void gemm_nt_f64_kernel(GemmNT g) {
             for (int q = 0; q < 4; ++q) {
                 int r = row0 + wm * WTM + i * 16 + fk + 4 * q;
                 int c = col0 + wn * WTN + j * 16 + fr;
-                double* cp = g.C + (int64_t)r * g.ldc + c;
-                double v = g.alpha * acc[i][j][q];
-                if (g.beta != 0.0) v += g.beta * (*cp);
+                double v = acc[i][j][q];
                 if (g.unit_diag_from >= 0 && r == c && r >= g.unit_diag_from) v = 1.0;
-                *cp = v;
+                cbase[(int64_t)(i * 16 + 4 * q) * g.ldc + j * 16] = v;
             }
 }
 
@@ -183,8 +201,12 @@ inline hipError_t launch_gemm_nt(const GemmNT& g, hipStream_t stream) {
     int ntm = g.M / BM, ntn = g.N / BN;
     int grid = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N>), dim3(grid),
-                       dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
+    if (g.w)
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), dim3(grid),
+                           dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), dim3(grid),
+                           dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
     return hipGetLastError();
 }
 

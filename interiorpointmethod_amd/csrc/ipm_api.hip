@@ -90,7 +90,7 @@ static Layout make_layout(int64_t m, int64_t n) {
     L.rows_per_chunk = (int)(L.mp / L.rc_chunks);
     while ((int64_t)L.rc_chunks * L.rows_per_chunk < L.mp) ++L.rows_per_chunk;   // (exact by construction)
     int64_t mx = m > n ? m : n;
-    int64_t vb = (mx + VBLK * 4 - 1) / (VBLK * 4);
+    int64_t vb = (mx + VBLK - 1) / VBLK;          // one element per thread until MAXPART blocks
     L.vblk = (int)(vb < 1 ? 1 : (vb > MAXPART ? MAXPART : vb));
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };

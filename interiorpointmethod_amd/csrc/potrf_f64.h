@@ -44,158 +44,244 @@ struct PotrfDiag {
     const int* done;
 };
 
+// sqrt(p) and 1/sqrt(p) from v_rsq_f64 (about 23 good bits) and one Halley step
+// (y1 = y0 (1 + r (1/2 + 3/8 r)), r = 1 - p y0^2: cubic, 23 -> 69 bits), i.e. a 7-deep
+// dependent chain instead of the ~45 instructions of the IEEE sqrt + divide sequences.  The
+// pivot chain (128 sequential pivots per block, 4096 per factorization) is the serial
+// bottleneck of the whole Cholesky, so its depth matters more than anything else here.
+__device__ __forceinline__ void sqrt_rsqrt(double p, double& root, double& rinv) {
+    double y = __builtin_amdgcn_rsq(p);
+    double t = p * y;
+    double r = __builtin_fma(-t, y, 1.0);
+    double c = __builtin_fma(r, 0.375, 0.5);
+    double e = r * c;
+    y = __builtin_fma(y, e, y);
+    rinv = y;
+    double g = p * y;
+    double d = __builtin_fma(-g, g, p);          // one correction step for the root itself
+    root = __builtin_fma(d, 0.5 * y, g);
+}
+
 // Workspace layout in LDS (one array, 128 x 130 doubles = 133 KB):
 //   L[i][j]   (j <= i)  at W[i*WLD + j]
 //   X[i][j]   (j <= i)  at W[j*WLD + i + 1]      X = inv(L), stored transposed one column right
 // so the strict upper part of the square holds the inverse without a second array.
+//
+// Schedule (jb = 16-wide panel index, 4 waves):
+//   P2(jb): threads 0..16*nrt-1 forward-substitute their row of the panel below tile jb
+//           (registers, T broadcast from LDS); wave 3 meanwhile inverts tile jb.
+//   P3(jb): wave 0 updates tile (jb+1,jb+1) and immediately factors it (runs ahead on the
+//           serial pivot chain); waves 1-3 do the rest of the trailing update and then block
+//           row jb of inv(L) (work that grows as the update shrinks).
+// Two barriers per panel.
+
+// factor the 16 x 16 tile at (c0,c0) in place; lane i (< 16) owns row i.  Wave-level.
+__device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double thresh, double big, double* dinv_s) {
+    const int i = lane & 15;
+    double t[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + i) * WLD + c0 + c]);
+        t[c] = v.x; t[c + 1] = v.y;
+    }
+    int nfix = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double p = readlane_f64(t[j], j);
+        if (!(p > thresh)) { p = big; ++nfix; }
+        double ljj, inv;
+        sqrt_rsqrt(p, ljj, inv);
+        if (lane == j) dinv_s[c0 + j] = inv;
+        t[j] = (i == j) ? ljj : t[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            double lc = readlane_f64(t[j], c);
+            if (i >= c) t[c] = __builtin_fma(-t[j], lc, t[c]);
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c <= i) W[(c0 + i) * WLD + c0 + c] = t[c];
+    }
+    return nfix;
+}
+
+// X = inv(T) for the factored tile at (c0,c0); lane c (< 16) computes column c.  Wave-level.
+__device__ __forceinline__ void invert_tile(double* W, int c0, int lane, const double* dinv_s) {
+    const int i = lane & 15;
+    double t[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + i) * WLD + c0 + c]);
+        t[c] = v.x; t[c + 1] = v.y;
+    }
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        x[k] *= dinv_s[c0 + k];                                  // X[k][i]
+#pragma unroll
+        for (int r = k + 1; r < 16; ++r)                         // eliminate column k from the rows below
+            x[r] = __builtin_fma(-readlane_f64(t[k], r), x[k], x[r]);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c >= i) W[(c0 + i) * WLD + c0 + c + 1] = x[c];   // X[c][i] -> row c0+i, col c0+c+1
+    }
+}
+
+// one row of the panel below tile (c0,c0): v = p * T^{-T} by forward substitution.  Thread-level.
+__device__ __forceinline__ void substitute_row(double* W, int c0, int row, const double* dinv_s) {
+    double p[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        f64x2 v = *reinterpret_cast<const f64x2*>(&W[row * WLD + c0 + c]);
+        p[c] = v.x; p[c + 1] = v.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        p[k] *= dinv_s[c0 + k];
+#pragma unroll
+        for (int c = k + 1; c < 16; ++c) p[c] = __builtin_fma(-p[k], W[(c0 + c) * WLD + c0 + k], p[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c += 2)
+        *reinterpret_cast<f64x2*>(&W[row * WLD + c0 + c]) = (f64x2){p[c], p[c + 1]};
+}
+
+// T(r0,q0) -= L(r0, c0:c0+16) L(q0, c0:c0+16)^T  (16 x 16 tiles, MFMA).  Wave-level.
+__device__ __forceinline__ void update_tile(double* W, int c0, int r0, int q0, int fr, int fk) {
+    f64x4 acc0, acc1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc0[q] = W[(r0 + fk + 4 * q) * WLD + q0 + fr];
+    double av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        av[kk] = -W[(r0 + fr) * WLD + c0 + kk * 4 + fk];
+        bv[kk] = W[(q0 + fr) * WLD + c0 + kk * 4 + fk];
+    }
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) W[(r0 + fk + 4 * q) * WLD + q0 + fr] = acc0[q] + acc1[q];
+}
+
+// X(ib,jt) = -X(ib,ib) * sum_{k=jt}^{ib-1} L(ib,k) X(k,jt)  (tile indices).  Wave-level.
+__device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, int fk) {
+    f64x4 s0 = (f64x4){0.0, 0.0, 0.0, 0.0}, s1 = s0;
+    for (int kb = jt; kb < ib; ++kb) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            av[kk] = W[(ib * 16 + fr) * WLD + kb * 16 + kk * 4 + fk];                   // L(ib,kb)[fr][k]
+            int kr = kb * 16 + kk * 4 + fk, cc = jt * 16 + fr;                          // X[kr][cc]
+            bv[kk] = (kr >= cc) ? W[cc * WLD + kr + 1] : 0.0;
+        }
+        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], s1, 0, 0, 0);
+    }
+    f64x4 s = s0 + s1;
+    // second product: accumulator register q of S is row fk+4q, so it pairs with X(ib,ib)[fr][fk+4q]
+    double xa[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int k = fk + 4 * q;
+        xa[q] = (k <= fr) ? -W[(ib * 16 + k) * WLD + ib * 16 + fr + 1] : 0.0;
+    }
+    f64x4 r0 = (f64x4){0.0, 0.0, 0.0, 0.0}, r1 = r0;
+    r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], s[0], r0, 0, 0, 0);
+    r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], s[1], r1, 0, 0, 0);
+    r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], s[2], r0, 0, 0, 0);
+    r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], s[3], r1, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)                                                          // X(ib,jt)[fk+4q][fr]
+        W[(jt * 16 + fr) * WLD + ib * 16 + fk + 4 * q + 1] = r0[q] + r1[q];
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
     if (a.done && *a.done) return;
     __shared__ __attribute__((aligned(16))) double W[NB * WLD];
-    __shared__ int s_fixed;
+    __shared__ double dinv_s[NB];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     const double thresh = a.eps * (*a.maxdiag);
 
-    if (tid == 0) s_fixed = 0;
-    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile)
-    for (int idx = tid; idx < NB * (NB / 2); idx += 256) {
-        int i = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
-        if (c2 <= (i | 15)) {
-            f64x2 v = *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2);
-            W[i * WLD + c2] = v.x;
-            W[i * WLD + c2 + 1] = v.y;
+    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile), 8 loads in flight
+#pragma unroll
+    for (int batch = 0; batch < 4; ++batch) {
+        f64x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int idx = tid + (batch * 8 + u) * 256;
+            int i = idx >> 6, c2 = (idx & 63) * 2;
+            v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int idx = tid + (batch * 8 + u) * 256;
+            int i = idx >> 6, c2 = (idx & 63) * 2;
+            if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
     }
     __syncthreads();
 
+    int nfix = 0;
+    if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, a.big, dinv_s);
+    __syncthreads();
+
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16;
-        // ---- (a) 16 x 16 pivot tile: factor + invert on wave 0, rows on lanes 0..15
-        if (wave == 0) {
-            const int i = fr;                 // lanes >= 16 mirror lanes 0..15 (results unused)
-            double t[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) t[c] = W[(c0 + i) * WLD + c0 + c];
-            double dinv[16];
-            int nfix = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double p = readlane_f64(t[j], j);
-                if (!(p > thresh)) { p = a.big; ++nfix; }
-                double ljj = sqrt(p);
-                double inv = 1.0 / ljj;
-                dinv[j] = inv;
-                t[j] = (i == j) ? ljj : t[j] * inv;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) {
-                    double lc = readlane_f64(t[j], c);
-                    if (i >= c) t[c] -= t[j] * lc;
-                }
-            }
-            // inverse of the tile: lane c owns column c of X = inv(T)
-            double x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                double acc = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < r; ++k) acc -= readlane_f64(t[k], r) * x[k];
-                x[r] = acc * dinv[r];
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (c <= i) W[(c0 + i) * WLD + c0 + c] = t[c];             // L tile
-                    if (c >= i) W[(c0 + i) * WLD + c0 + c + 1] = x[c];         // X[c][i] -> row i
-                }
-                if (lane == 0 && nfix) s_fixed += nfix;
-            }
-        }
+        const int nrt = NB / 16 - jb - 1;                 // 16-row tiles below the pivot tile
+        // ---- P2: panel rows by substitution; tile inverse on wave 3
+        if (tid < 16 * nrt) substitute_row(W, c0, c0 + 16 + tid, dinv_s);
+        if (wave == 3) invert_tile(W, c0, lane, dinv_s);
         __syncthreads();
-        // ---- (b) panel below the tile: P <- P * X^T  (X = inv(T)), one 16-row tile per wave turn
-        const int nrt = NB / 16 - jb - 1;      // row tiles below
-        for (int rt = wave; rt < nrt; rt += 4) {
-            const int r0 = (jb + 1 + rt) * 16;
-            double pa[4], xb[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                pa[kk] = W[(r0 + fr) * WLD + c0 + kk * 4 + fk];                // P[r][k]
-                int k = kk * 4 + fk;                                           // X[fr][k], k <= fr
-                xb[kk] = (k <= fr) ? W[(c0 + k) * WLD + c0 + fr + 1] : 0.0;
-            }
-            f64x4 acc = (f64x4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], xb[kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) W[(r0 + fk + 4 * q) * WLD + c0 + fr] = acc[q];
-        }
-        __syncthreads();
-        // ---- (c) trailing update inside the block: T(ib,cb) -= L(ib,jb) L(cb,jb)^T, jb<cb<=ib
-        {
+        // ---- P3: trailing update (wave 0: next pivot tile, then factor it) + block row jb of inv(L)
+        if (wave == 0 && nrt > 0) {
+            update_tile(W, c0, c0 + 16, c0 + 16, fr, fk);
+            nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s);
+        } else if (nrt == 0) {
+            for (int jt = wave; jt < jb; jt += 4) inverse_tile(W, jb, jt, fr, fk);   // last block row: all waves
+        } else {
             const int ntile = nrt * (nrt + 1) / 2;
-            for (int tix = wave; tix < ntile; tix += 4) {
+            int item = wave - 1;                           // work items: update tiles 1..ntile-1, then inverse tiles
+            for (int tix = 1 + item; tix < ntile; tix += 3) {
                 int ib = (int)((sqrtf(8.0f * (float)tix + 1.0f) - 1.0f) * 0.5f);
                 while ((ib + 1) * (ib + 2) / 2 <= tix) ++ib;
                 while (ib * (ib + 1) / 2 > tix) --ib;
                 int cb = tix - ib * (ib + 1) / 2;
-                const int r0 = (jb + 1 + ib) * 16, q0 = (jb + 1 + cb) * 16;
-                f64x4 acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = W[(r0 + fk + 4 * q) * WLD + q0 + fr];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    double av = -W[(r0 + fr) * WLD + c0 + kk * 4 + fk];
-                    double bv = W[(q0 + fr) * WLD + c0 + kk * 4 + fk];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) W[(r0 + fk + 4 * q) * WLD + q0 + fr] = acc[q];
+                update_tile(W, c0, (jb + 1 + ib) * 16, (jb + 1 + cb) * 16, fr, fk);
             }
-        }
-        __syncthreads();
-    }
-
-    // ---- inverse of the whole block, one 16-row block row at a time:
-    //      X(i,j) = -X(i,i) * sum_{k=j}^{i-1} L(i,k) X(k,j),  j < i
-    for (int ib = 1; ib < NB / 16; ++ib) {
-        for (int jt = wave; jt < ib; jt += 4) {
-            f64x4 s = (f64x4){0.0, 0.0, 0.0, 0.0};
-            for (int kb = jt; kb < ib; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    double av = W[(ib * 16 + fr) * WLD + kb * 16 + kk * 4 + fk];        // L(i,k)[r][k]
-                    int kr = kb * 16 + kk * 4 + fk, cc = jt * 16 + fr;                  // X[kr][cc]
-                    double bv = (kr >= cc) ? W[cc * WLD + kr + 1] : 0.0;
-                    s = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, s, 0, 0, 0);
-                }
-            }
-            // second product: accumulator register q of S is row fk+4q, so pair it with
-            // X(i,i)[fr][fk+4q] (any order of k is fine as long as both operands agree)
-            f64x4 r = (f64x4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int k = fk + 4 * q;
-                double av = (k <= fr) ? -W[(ib * 16 + k) * WLD + ib * 16 + fr + 1] : 0.0;  // -X(i,i)[fr][k]
-                r = __builtin_amdgcn_mfma_f64_16x16x4f64(av, s[q], r, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)                                                  // X(i,j)[fk+4q][fr]
-                W[(jt * 16 + fr) * WLD + ib * 16 + fk + 4 * q + 1] = r[q];
+            for (int jt = item; jt < jb; jt += 3) inverse_tile(W, jb, jt, fr, fk);
         }
         __syncthreads();
     }
 
     // ---- write back: L (lower) to B, inverse to `inv` (dense, zero above the diagonal)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx / NB, j = idx % NB;
-        if (j <= i) a.Bkk[(int64_t)i * a.ld + j] = W[i * WLD + j];
+    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+        int i = idx >> 6, j = (idx & 63) * 2;
+        if (j <= i) {
+            double l0 = W[i * WLD + j], l1 = W[i * WLD + j + 1];
+            if (j + 1 <= i) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){l0, l1};
+            else a.Bkk[(int64_t)i * a.ld + j] = l0;
+        }
     }
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        int i = idx / NB, j = idx % NB;
-        a.inv[idx] = (j <= i) ? W[j * WLD + i + 1] : 0.0;
+    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+        int i = idx >> 6, j = (idx & 63) * 2;
+        double x0 = (j <= i) ? W[j * WLD + i + 1] : 0.0;
+        double x1 = (j + 1 <= i) ? W[(j + 1) * WLD + i + 1] : 0.0;
+        *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){x0, x1};
     }
-    if (tid == 0 && s_fixed) atomicAdd(a.fixed, s_fixed);
+    if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
 }
 
 // max of the diagonal of an n x n matrix (single workgroup; n <= a few 10^4)

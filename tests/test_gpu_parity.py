@@ -180,7 +180,8 @@ def test_dense_end_to_end(golden_dir, nm):
     assert abs(info["objective"] - ref) <= 1e-6 * max(1.0, abs(ref))
     assert info["rp"] <= 1e-6 and info["rd"] <= 1e-6 and info["gap"] <= 1e-8
     assert abs(info["iterations"] - int(z["iterations"])) <= 2
-    assert rel(x, z["x"]) < 1e-5
+    if nm.startswith("syn"):                       # ex2's optimal face is not a single point
+        assert rel(x, z["x"]) < 1e-5
     assert x.shape == (A.shape[1], 1) and y.shape == (A.shape[0], 1) and s.shape == x.shape
 
 

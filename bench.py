@@ -56,6 +56,74 @@ def cpu_baseline(A, b, c, budget_s=20.0, max_its=6):
                           its, m, n, dt, os.cpu_count() or 0)}
 
 
+PARITY_SET = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "GROW7", "KB2", "MAROS-R7", "SC105",
+              "SC205", "SC50A", "SC50B", "SCSD1", "SCSD6", "SCSD8", "SCTAP1", "SCTAP2", "SCTAP3", "SHARE2B",
+              "STOCFOR1", "STOCFOR2", "STOCFOR3", "TRUSS", "WOODW"]
+
+
+def netlib_main(args):
+    """Batched-LP mode (BASELINE.json configs[3]): the Netlib fixtures sharded over the ranks, one LP per
+    GPU at a time, a single RCCL all-gather of the statistics records at the end."""
+    import glob
+    import numpy as np
+    import torch
+    from interiorpointmethod_amd import batch
+    from interiorpointmethod_amd.matio import load_npz_problem
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    names, probs, costs = [], [], []
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netlib", "*.npz"))):
+        nm = os.path.basename(f)[:-4]
+        if args.netlib_set == "parity" and nm not in PARITY_SET:
+            continue
+        A, b, c, cTlb, valid = load_npz_problem(f)
+        if not valid or A.shape[0] > args.max_m:
+            continue
+        names.append(nm)
+        probs.append((A, b, c))
+        colnnz = np.diff(A.indptr).astype(np.float64)
+        costs.append(batch.predicted_cost(A.shape[0], A.shape[1]))     # dense-A contraction today
+    # warm-up: one small solve per rank (library load, first-launch costs) outside the timed region
+    batch.solve_one(probs[names.index("AFIRO")] if "AFIRO" in names else probs[0], device=local_rank)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    rec, _ = batch.run_batch(probs, costs=costs, device=local_rank, dist=dist,
+                             gather_device=torch.device("cuda", local_rank) if dist is not None else None,
+                             tol=1e-8, max_iter=300)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        summ = batch.summarize(rec)
+        out = {"metric": "Netlib LPs/sec (benchmarks/ suite, batched, tol=1e-8, cap 300)",
+               "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
+               "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
+               "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s), 1 LP per GPU at a time" % (
+                   args.netlib_set, len(names), max(world, 1))},
+               "summary": summ, "wall_seconds": elapsed,
+               "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
+                          for r in rec}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,7 +132,15 @@ def main():
     ap.add_argument("--m", type=int, default=M_DEFAULT)
     ap.add_argument("--n", type=int, default=N_DEFAULT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="dense", choices=["dense", "netlib"],
+                    help="dense: IPM iterations/s on the synthetic LP (default, the headline metric); "
+                         "netlib: LPs/s over the committed Netlib fixtures, sharded over the ranks")
+    ap.add_argument("--netlib-set", default="all", choices=["all", "parity"],
+                    help="all 73 valid files, or the 26 on which the reference converges")
+    ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
     args = ap.parse_args()
+    if args.workload == "netlib":
+        return netlib_main(args)
 
     import numpy as np
     import torch

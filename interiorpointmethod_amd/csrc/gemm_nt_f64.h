@@ -40,6 +40,12 @@ struct GemmNT {
     int lower;                  // 1: only tiles with tile_row >= tile_col (needs BM == BN, M == N)
     int unit_diag_from;         // >= 0: C[r][r] = 1 for r >= unit_diag_from (padding rows); -1 off
     const int* done;            // device flag: kernel is a no-op when *done != 0 (may be null)
+    // split-K of the tail tiles (filled by launch_gemm_nt): logical tiles [0, n_direct) are computed
+    // whole by one workgroup each; every tile >= n_direct is cut into split_p K-chunks whose partial
+    // tiles go to `slab` and are summed in chunk order by splitk_reduce_kernel (deterministic).
+    int n_direct, split_p, chunk_stages;
+    double* slab;
+    int tile_offset;            // logical tile = tile_offset + index (used to skip the first lower tile)
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -77,10 +83,21 @@ void gemm_nt_f64_kernel(GemmNT g) {
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // ---- tile coordinates
+    // ---- tile coordinates (+ K range when this workgroup owns a split-K chunk of a tail tile)
     int ti, tj;
+    int kbeg = 0, kend = g.K / BK;
+    double* slab_out = nullptr;
     {
-        int bid = xcd_remap(blockIdx.x, gridDim.x);
+        int bid;
+        if ((int)blockIdx.x < g.n_direct) {
+            bid = xcd_remap(blockIdx.x, g.n_direct) + g.tile_offset;
+        } else {
+            int r = (int)blockIdx.x - g.n_direct;
+            bid = g.n_direct + r / g.split_p;
+            kbeg = (r % g.split_p) * g.chunk_stages;
+            kend = min(kend, kbeg + g.chunk_stages);
+            slab_out = g.slab + (size_t)r * (BM * BN);
+        }
         if (g.lower) {
             // bid -> (ti, tj), ti >= tj, row-major enumeration of the lower triangle
             int t = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
@@ -131,13 +148,13 @@ void gemm_nt_f64_kernel(GemmNT g) {
         }
     };
 
-    const int nk = g.K / BK;
-    load_stage(0);
-    store_stage(0);
+    const int nk = kend;
+    load_stage(kbeg * BK);
+    store_stage(kbeg & 1);
     __syncthreads();
 
     const int fr = lane & 15, fk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kbeg; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_stage((kt + 1) * BK);        // in flight during the MFMAs below
         const double* pa = Ps + (buf * BM + wm * WTM + fr) * LDT + fk;
@@ -162,6 +179,16 @@ void gemm_nt_f64_kernel(GemmNT g) {
     // ---- epilogue: D[row=(l>>4)+4q][col=l&15].  beta is 0 or 1 on this path; for beta != 0 all
     // C loads are issued before the first use so they overlap (a load-use-store chain per
     // element costs an L2 round trip each: 64 serialized round trips per thread).
+    if (slab_out) {                                     // split-K partial: raw tile, summed later
+        double* sb = slab_out + (wm * WTM + fk) * BN + wn * WTN + fr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sb[(i * 16 + 4 * q) * BN + j * 16] = acc[i][j][q];
+        return;
+    }
     double* cbase = g.C + (int64_t)(row0 + wm * WTM + fk) * g.ldc + col0 + wn * WTN + fr;
     if (g.beta != 0.0) {
 #pragma unroll
@@ -196,17 +223,79 @@ void gemm_nt_f64_kernel(GemmNT g) {
             }
 }
 
+// C tile = beta*C + alpha * (sum of the split_p slabs of that tile, in chunk order); one tail tile per
+// blockIdx.y, 1024 elements per workgroup.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmNT g) {
+    if (g.done && *g.done) return;
+    const int tile = g.n_direct + blockIdx.y;
+    int ti, tj;
+    if (g.lower) {
+        int t = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        while ((t + 1) * (t + 2) / 2 <= tile) ++t;
+        while (t * (t + 1) / 2 > tile) --t;
+        ti = t; tj = tile - t * (t + 1) / 2;
+    } else {
+        int ntn = g.N / BN;
+        ti = tile / ntn; tj = tile % ntn;
+    }
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;          // 4 consecutive elements of one tile row
+    const int r = e / BN, c = e % BN;
+    const double* sl = g.slab + (size_t)blockIdx.y * g.split_p * (BM * BN) + e;
+    f64x2 s0 = (f64x2){0.0, 0.0}, s1 = s0;
+    for (int p = 0; p < g.split_p; ++p) {
+        f64x2 a = *reinterpret_cast<const f64x2*>(sl + (size_t)p * (BM * BN));
+        f64x2 b = *reinterpret_cast<const f64x2*>(sl + (size_t)p * (BM * BN) + 2);
+        s0 += a; s1 += b;
+    }
+    double v[4] = {s0.x, s0.y, s1.x, s1.y};
+    const int row = ti * BM + r, col = tj * BN + c;
+    double* cp = g.C + (int64_t)row * g.ldc + col;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double o = g.alpha * v[q];
+        if (g.beta != 0.0) o += g.beta * cp[q];
+        if (g.unit_diag_from >= 0 && row == col + q && row >= g.unit_diag_from) o = 1.0;
+        cp[q] = o;
+    }
+}
+
+constexpr int kSlabTiles = 512;      // capacity of the split-K slab workspace, in BM x BN tiles
+
+// slots = workgroups resident at once (2 per CU for the 128x128 tile).  slab may be null (no split).
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-inline hipError_t launch_gemm_nt(const GemmNT& g, hipStream_t stream) {
+inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nullptr, int slots = 512,
+                                 int skip_first = 0) {
     int ntm = g.M / BM, ntn = g.N / BN;
-    int grid = g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn;
-    if (grid <= 0) return hipSuccess;
+    int tiles = (g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn) - skip_first;
+    g.tile_offset = skip_first;
+    if (tiles <= 0) return hipSuccess;
+    const int nk = g.K / BK;
+    g.n_direct = tiles; g.split_p = 1; g.chunk_stages = nk; g.slab = nullptr;
+    int grid = tiles;
+    if (slab && slots > 0) {
+        int tail = tiles % slots;
+        if (tail > 0 && nk >= 16) {
+            int p = slots / tail;
+            if (p > nk / 8) p = nk / 8;                      // keep >= 8 stages per chunk
+            if ((long)tail * p > kSlabTiles) p = kSlabTiles / tail;
+            if (p >= 2) {
+                int per = (nk + p - 1) / p;
+                p = (nk + per - 1) / per;
+                g.n_direct = tiles - tail; g.split_p = p; g.chunk_stages = per; g.slab = slab;
+                grid = g.n_direct + tail * p;
+            }
+        }
+    }
     if (g.w)
         hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), dim3(grid),
                            dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
     else
         hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), dim3(grid),
                            dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
+    if (g.slab)
+        hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(BM * BN / 1024, tiles - g.n_direct), dim3(256), 0,
+                           stream, g);
     return hipGetLastError();
 }
 

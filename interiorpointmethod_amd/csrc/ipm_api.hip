@@ -28,6 +28,10 @@ struct ipm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;            // bulk stream of the Cholesky look-ahead
+    std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
+    hipEvent_t ev_fork = nullptr;
+    int lookahead = 1;
     int64_t m = 0, n = 0, mp = 0, np = 0;
     int nblk = 0, rc_chunks = 0, rows_per_chunk = 0, vblk = 0;
     ipm_options opt;
@@ -39,7 +43,9 @@ struct ipm_handle {
     double *x = nullptr, *s = nullptr, *c = nullptr, *rc = nullptr, *d = nullptr, *v = nullptr, *q = nullptr;
     double *dxa = nullptr, *dsa = nullptr, *dx = nullptr, *ds = nullptr;
     double *y = nullptr, *b = nullptr, *rb = nullptr, *t1 = nullptr, *t2 = nullptr, *dya = nullptr, *dy = nullptr;
-    double *atp = nullptr, *part = nullptr;
+    double *atp = nullptr, *part = nullptr, *slab = nullptr;
+    int form_variant = 0;
+    long long* stamp_buf = nullptr;       // diagnostic only (IPM_POTRF_STAMPS=1)
     Scalars* sc = nullptr;
     int* fixed = nullptr;
     Scalars* h_sc = nullptr;          // pinned host mirror
@@ -75,7 +81,7 @@ static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * 
 struct Layout {
     int64_t mp, np;
     int nblk, rc_chunks, rows_per_chunk, vblk;
-    size_t off_A, off_B, off_inv, off_nvec, off_mvec, off_atp, off_part, off_sc, off_fixed, total;
+    size_t off_A, off_B, off_inv, off_nvec, off_mvec, off_atp, off_part, off_sc, off_fixed, off_slab, total;
 };
 static const int N_NVEC = 11;   // x s c rc d v q dxa dsa dx ds
 static const int N_MVEC = 7;    // y b rb t1 t2 dya dy
@@ -103,6 +109,7 @@ static Layout make_layout(int64_t m, int64_t n) {
     L.off_part = take(sizeof(double) * P_NSLOT * MAXPART);
     L.off_sc = take(sizeof(Scalars));
     L.off_fixed = take(256);
+    L.off_slab = take(sizeof(double) * (size_t)kSlabTiles * 128 * 128);   // split-K partial tiles (64 MB)
     L.total = off;
     return L;
 }
@@ -201,12 +208,24 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->part = (double*)(base + L.off_part);
     h->sc = (Scalars*)(base + L.off_sc);
     h->fixed = (int*)(base + L.off_fixed);
+    h->slab = (double*)(base + L.off_slab);
+    if (const char* e = getenv("IPM_FORM_VARIANT")) h->form_variant = atoi(e);
     // zero everything except A and B (padding entries of every vector must stay 0)
-    CREATE_TRY(hipMemsetAsync(base + L.off_inv, 0, L.total - L.off_inv, h->stream));
+    CREATE_TRY(hipMemsetAsync(base + L.off_inv, 0, L.off_slab - L.off_inv, h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->h_sc, sizeof(Scalars), hipHostMallocDefault));
     memset(h->h_sc, 0, sizeof(Scalars));
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
+    if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
+    if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 4 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 4 * 64 * sizeof(long long))); }
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
+    for (int k = 0; k < h->nblk; ++k) {
+        CREATE_TRY(hipEventCreateWithFlags(&h->ev_diag[k], hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&h->ev_crit[k], hipEventDisableTiming));
+        CREATE_TRY(hipEventCreateWithFlags(&h->ev_bulk[k], hipEventDisableTiming));
+    }
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 5000, 0, 1);
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -219,9 +238,15 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (!h) return IPM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk})
+        for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) (void)hipHostFree(h->h_sc);
+    if (h->stamp_buf) (void)hipFree(h->stamp_buf);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -364,22 +389,40 @@ static int enqueue_form(ipm_handle* h, const double* d) {
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;
     g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = (int)h->m; g.done = &h->sc->done;
-    HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream)));
+    switch (h->form_variant) {
+        case 1: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream))); break;               // no split-K
+        case 2: HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(g, h->stream, h->slab, 256))); break;  // BK=32, 1 wg/CU
+        default: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;
+    }
     return IPM_OK;
 }
 
-// blocked guarded Cholesky of B in place (lower)
+// blocked guarded Cholesky of B in place (lower), right-looking with one step of look-ahead:
+//   main stream : potrf_diag(k) -> [wait bulk(k-1)] -> panel rows of block k+1 -> update of tile (k+1,k+1)
+//   bulk stream : [wait diag(k)] panel rows >= k+2 -> [wait crit(k)] rest of the trailing update
+// so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
 static int enqueue_factor(ipm_handle* h) {
     const int* done = &h->sc->done;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
+    const bool la = h->lookahead != 0 && h->nblk > 2;
+    hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
+    if (la) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork, sm));
+        HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_fork, 0));
+    }
     for (int k = 0; k < h->nblk; ++k) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
         pd.inv = h->invD + (int64_t)k * NB * NB;
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big;
-        pd.fixed = &h->sc->fixed; pd.done = done;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, h->stream, pd);
+        pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
+        if (h->stamp_buf && k == 0) {
+            pd.stamps = h->stamp_buf;
+            hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), 0, sm, pd);
+        } else {
+            hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(256), 0, sm, pd);
+        }
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
         if (rem <= 0) break;
         double* panel = h->B + (int64_t)(k + 1) * NB * h->mp + (int64_t)k * NB;
@@ -387,13 +430,32 @@ static int enqueue_factor(ipm_handle* h) {
         t.P = panel; t.ldp = h->mp; t.Q = pd.inv; t.ldq = NB; t.w = nullptr;
         t.C = panel; t.ldc = h->mp; t.M = rem; t.N = NB; t.K = NB;
         t.alpha = 1.0; t.beta = 0.0; t.lower = 0; t.unit_diag_from = -1; t.done = done;
-        HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(t, h->stream)));
         GemmNT u;                                                   // B_ij -= L_ik L_jk^T
         u.P = panel; u.ldp = h->mp; u.Q = panel; u.ldq = h->mp; u.w = nullptr;
         u.C = h->B + (int64_t)(k + 1) * NB * (h->mp + 1); u.ldc = h->mp; u.M = rem; u.N = rem; u.K = NB;
         u.alpha = -1.0; u.beta = 1.0; u.lower = 1; u.unit_diag_from = -1; u.done = done;
-        HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, h->stream)));
+        if (!la) {
+            HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(t, sm)));
+            HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sm)));
+            continue;
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_diag[k], sm));
+        if (k >= 1) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[k - 1], 0));
+        GemmNT tc = t; tc.M = NB;                                   // critical panel rows: block row k+1
+        HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
+        HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
+        GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1), as 64x64 sub-tiles
+        HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(uc, sm)));
+        HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_diag[k], 0));
+        if (rem > NB) {
+            GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
+            HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
+            HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
+            HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sb, nullptr, 512, /*skip_first=*/1)));
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }
+    if (la) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[h->nblk - 2], 0));
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }
@@ -523,6 +585,13 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
     }
     if ((rc = read_scalars(h))) return rc;
     fill_stats(h, stats, 0.0);
+    return IPM_OK;
+}
+
+// diagnostic: copy the s_memtime stamps of the first diagonal-block factorization (4 waves x 64 slots)
+extern "C" int ipm_debug_get_stamps(ipm_handle* h, long long* out) {
+    if (!h || !out || !h->stamp_buf) return fail(h, IPM_ERR_STATE, "stamps not enabled (IPM_POTRF_STAMPS=1)");
+    HIP_TRY(h, hipMemcpy(out, h->stamp_buf, 4 * 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return IPM_OK;
 }
 

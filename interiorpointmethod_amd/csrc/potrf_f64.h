@@ -42,6 +42,7 @@ struct PotrfDiag {
     double eps, big;
     int* fixed;                  // device counter of guarded pivots (accumulates)
     const int* done;
+    long long* stamps;           // diagnostic build only (STAMP = true): s_memtime per phase and wave
 };
 
 // sqrt(p) and 1/sqrt(p) from v_rsq_f64 (about 23 good bits) and one Halley step
@@ -75,7 +76,19 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& root, double& rinv)
 //           row jb of inv(L) (work that grows as the update shrinks).
 // Two barriers per panel.
 
-// factor the 16 x 16 tile at (c0,c0) in place; lane i (< 16) owns row i.  Wave-level.
+// 1/p from v_rcp_f64 (about 23 good bits) and one cubic step y(1 + e + e^2), e = 1 - p y.
+__device__ __forceinline__ double fast_rcp(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, y, 1.0);
+    double t = __builtin_fma(e, e, e);
+    return __builtin_fma(y, t, y);
+}
+
+// Factor the 16 x 16 tile at (c0,c0) in place; lane i (< 16) owns row i (lanes >= 16 mirror).
+// Wave-level, registers + v_readlane only (an LDS round trip per pivot measured slower).
+// The elimination keeps UNSCALED columns, T[r][j] = L[r][j] L[j][j], so that a pivot step has
+// only 1/p_j on its dependent chain and the v_readlane broadcasts of column j do not wait for it:
+//   T[r][c] -= T[r][j] * (T[c][j] / p_j) ;  the 1/sqrt(p) scaling happens once at the end.
 __device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double thresh, double big, double* dinv_s) {
     const int i = lane & 15;
     double t[16];
@@ -84,25 +97,29 @@ __device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double t
         f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + i) * WLD + c0 + c]);
         t[c] = v.x; t[c + 1] = v.y;
     }
+    double dinv[16];
     int nfix = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         double p = readlane_f64(t[j], j);
-        if (!(p > thresh)) { p = big; ++nfix; }
-        double ljj, inv;
-        sqrt_rsqrt(p, ljj, inv);
-        if (lane == j) dinv_s[c0 + j] = inv;
-        t[j] = (i == j) ? ljj : t[j] * inv;
+        if (!(p > thresh)) { p = big; ++nfix; if (i == j) t[j] = big; }
+        const double rp = fast_rcp(p);
+        double root;
+        sqrt_rsqrt(p, root, dinv[j]);                     // off the dependent chain
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
-            double lc = readlane_f64(t[j], c);
+            double lc = readlane_f64(t[j], c) * rp;       // T[c][j] / p_j  (wave-uniform)
             if (i >= c) t[c] = __builtin_fma(-t[j], lc, t[c]);
         }
     }
     if (lane < 16) {
+        dinv_s[c0 + i] = [&] { double d = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d = (i == j) ? dinv[j] : d;
+            return d; }();
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            if (c <= i) W[(c0 + i) * WLD + c0 + c] = t[c];
+            if (c <= i) W[(c0 + i) * WLD + c0 + c] = t[c] * dinv[c];     // L[i][c] = T[i][c] / sqrt(p_c)
     }
     return nfix;
 }
@@ -205,6 +222,10 @@ __device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, 
         W[(jt * 16 + fr) * WLD + ib * 16 + fk + 4 * q + 1] = r0[q] + r1[q];
 }
 
+// STAMP = true is a diagnostic instantiation (tools/potrf_stamps.py): every wave records s_memtime
+// at each phase boundary into a.stamps[wave*64 + slot]; the production kernel carries no stamps.
+#define IPM_STAMP(slot) do { if (STAMP && lane == 0) a.stamps[wave * 64 + (slot)] = (long long)clock64(); } while (0)
+template <bool STAMP>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
     if (a.done && *a.done) return;
     __shared__ __attribute__((aligned(16))) double W[NB * WLD];
@@ -215,59 +236,84 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
     const int fr = lane & 15, fk = lane >> 4;
     const double thresh = a.eps * (*a.maxdiag);
 
-    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile), 8 loads in flight
+    IPM_STAMP(0);
+    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all 32 loads of a
+    //      thread are issued before the first LDS write (one memory latency instead of four)
+    {
+        f64x2 v[32];
 #pragma unroll
-    for (int batch = 0; batch < 4; ++batch) {
-        f64x2 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int idx = tid + (batch * 8 + u) * 256;
+        for (int u = 0; u < 32; ++u) {
+            int idx = tid + u * 256;
             int i = idx >> 6, c2 = (idx & 63) * 2;
             v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int idx = tid + (batch * 8 + u) * 256;
+        for (int u = 0; u < 32; ++u) {
+            int idx = tid + u * 256;
             int i = idx >> 6, c2 = (idx & 63) * 2;
             if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
     }
     __syncthreads();
+    IPM_STAMP(1);
 
     int nfix = 0;
     if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, a.big, dinv_s);
+    IPM_STAMP(2);
     __syncthreads();
+    IPM_STAMP(3);
 
+    // Phase schedule per 16-wide panel jb (two barriers per panel):
+    //   P2(jb): forward substitution of the panel rows below tile jb (threads 0..16*nrt-1)
+    //   P3(jb): wave 0 : update tile (jb+1,jb+1) and factor it (runs ahead on the serial pivot chain)
+    //           wave 3 : invert tile jb, then shares the item list
+    //           waves 1,2: item list = rest of the trailing update of panel jb, then block row jb-1 of
+    //                      inv(L) (its diagonal tile inverse was produced in P3(jb-1))
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16;
         const int nrt = NB / 16 - jb - 1;                 // 16-row tiles below the pivot tile
-        // ---- P2: panel rows by substitution; tile inverse on wave 3
         if (tid < 16 * nrt) substitute_row(W, c0, c0 + 16 + tid, dinv_s);
-        if (wave == 3) invert_tile(W, c0, lane, dinv_s);
+        IPM_STAMP(4 + jb * 4);
         __syncthreads();
-        // ---- P3: trailing update (wave 0: next pivot tile, then factor it) + block row jb of inv(L)
+        IPM_STAMP(5 + jb * 4);
         if (wave == 0 && nrt > 0) {
             update_tile(W, c0, c0 + 16, c0 + 16, fr, fk);
             nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s);
-        } else if (nrt == 0) {
-            for (int jt = wave; jt < jb; jt += 4) inverse_tile(W, jb, jt, fr, fk);   // last block row: all waves
         } else {
+            if (wave == 3) invert_tile(W, c0, lane, dinv_s);
+            // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1
             const int ntile = nrt * (nrt + 1) / 2;
-            int item = wave - 1;                           // work items: update tiles 1..ntile-1, then inverse tiles
-            for (int tix = 1 + item; tix < ntile; tix += 3) {
-                int ib = (int)((sqrtf(8.0f * (float)tix + 1.0f) - 1.0f) * 0.5f);
-                while ((ib + 1) * (ib + 2) / 2 <= tix) ++ib;
-                while (ib * (ib + 1) / 2 > tix) --ib;
-                int cb = tix - ib * (ib + 1) / 2;
-                update_tile(W, c0, (jb + 1 + ib) * 16, (jb + 1 + cb) * 16, fr, fk);
+            const int nupd = ntile > 0 ? ntile - 1 : 0;
+            const int ninv = jb >= 1 ? jb - 1 : 0;
+            const int nw = (nrt > 0) ? 3 : 4;             // last panel: wave 0 has no pivot tile left
+            const int me = (nrt > 0) ? wave - 1 : wave;
+            for (int it = me; it < nupd + ninv; it += nw) {
+                if (it < nupd) {
+                    int tix = it + 1;
+                    int ib = (int)((sqrtf(8.0f * (float)tix + 1.0f) - 1.0f) * 0.5f);
+                    while ((ib + 1) * (ib + 2) / 2 <= tix) ++ib;
+                    while (ib * (ib + 1) / 2 > tix) --ib;
+                    int cb = tix - ib * (ib + 1) / 2;
+                    update_tile(W, c0, (jb + 1 + ib) * 16, (jb + 1 + cb) * 16, fr, fk);
+                } else {
+                    inverse_tile(W, jb - 1, it - nupd, fr, fk);
+                }
             }
-            for (int jt = item; jt < jb; jt += 3) inverse_tile(W, jb, jt, fr, fk);
         }
+        IPM_STAMP(6 + jb * 4);
         __syncthreads();
+        IPM_STAMP(7 + jb * 4);
     }
+    // last block row of inv(L): needs the tile inverse of panel 7 (made in P3(7)) and row 6 (also P3(7))
+    for (int jt = wave; jt < NB / 16 - 1; jt += 4) inverse_tile(W, NB / 16 - 1, jt, fr, fk);
+    IPM_STAMP(38);
+    __syncthreads();
+    IPM_STAMP(39);
 
     // ---- write back: L (lower) to B, inverse to `inv` (dense, zero above the diagonal)
-    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+#pragma unroll 8
+    for (int u = 0; u < 32; ++u) {
+        int idx = tid + u * 256;
         int i = idx >> 6, j = (idx & 63) * 2;
         if (j <= i) {
             double l0 = W[i * WLD + j], l1 = W[i * WLD + j + 1];
@@ -275,12 +321,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
             else a.Bkk[(int64_t)i * a.ld + j] = l0;
         }
     }
-    for (int idx = tid; idx < NB * NB / 2; idx += 256) {
+#pragma unroll 8
+    for (int u = 0; u < 32; ++u) {
+        int idx = tid + u * 256;
         int i = idx >> 6, j = (idx & 63) * 2;
         double x0 = (j <= i) ? W[j * WLD + i + 1] : 0.0;
         double x1 = (j + 1 <= i) ? W[(j + 1) * WLD + i + 1] : 0.0;
         *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){x0, x1};
     }
+    IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
 }
 

@@ -58,7 +58,8 @@ typedef struct ipm_options {
     double pivot_guard_big;  /* replacement pivot, default 1e64 */
     int32_t check_every;     /* iterations enqueued between host status reads (>=1) */
     int32_t reserved0;
-    int64_t reserved1;
+    int64_t sparse_nnz;      /* > 0: handle keeps A sparse (CSR+CSC on the device, no dense image) with at
+                                most this many nonzeros; only ipm_set_A_csc may then supply A */
 } ipm_options;
 
 /* per-solve statistics; norms use the reference's scaling (main.py:170-171) */
@@ -86,6 +87,8 @@ void ipm_default_options(ipm_options* opts);
 /* ---- handle ----------------------------------------------------------------------- */
 /* Bytes of device workspace a handle for an m x n problem needs. */
 int ipm_workspace_bytes(int64_t m, int64_t n, size_t* bytes);
+/* Same for a handle created with ipm_options.sparse_nnz = nnz (A kept sparse). */
+int ipm_workspace_bytes_csc(int64_t m, int64_t n, int64_t nnz, size_t* bytes);
 
 /* workspace == NULL: the library allocates (and frees in ipm_destroy).
  * stream == NULL: the library creates its own stream on `device`. */
@@ -98,7 +101,9 @@ const char* ipm_last_error(const ipm_handle* h);   /* also valid with h == NULL 
 /* Row-major m x n fp64 matrix with leading dimension ld (elements). is_device: the
  * pointer is device memory on the handle's device (copied device-to-device). */
 int ipm_set_A_dense(ipm_handle* h, const double* A, int64_t ld, int is_device);
-/* CSC triplets as scipy.sparse.csc_matrix holds them (sparse_interior.py:215); host memory. */
+/* CSC triplets as scipy.sparse.csc_matrix holds them (sparse_interior.py:215); host memory.
+ * Duplicate entries are summed (scipy's constructor semantics).  On a sparse handle A stays sparse
+ * (SpMV + sparse formation of A D^2 A^T); on a dense handle it is scattered into the dense image. */
 int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t* rowind,
                   const double* val, int64_t nnz);
 int ipm_set_bc(ipm_handle* h, const double* b, const double* c);        /* host, length m / n */
@@ -138,6 +143,9 @@ int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl);
  * out[0]=form A D^2 A^T, out[1]=factor, out[2]=triangular solves, out[3]=everything else.
  * Only filled when profiling was requested with ipm_set_profiling(h, 1). */
 int ipm_set_profiling(ipm_handle* h, int enable);
+/* Diagnostic builds only (environment IPM_POTRF_STAMPS=1 at ipm_create): s_memtime stamps of the first
+ * diagonal-block factorization, 4 waves x 64 slots.  IPM_ERR_STATE otherwise. */
+int ipm_debug_get_stamps(ipm_handle* h, long long* out);
 int ipm_get_phase_ms(ipm_handle* h, double out[4]);
 
 #ifdef __cplusplus

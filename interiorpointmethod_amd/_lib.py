@@ -15,11 +15,11 @@ LIB_PATH = os.path.join(_HERE, "libipm_hip.so")
 
 # symbols declared in include/ipm_hip.h (checked by tests/test_abi.py against the header)
 EXPORTS = [
-    "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes",
+    "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
     "ipm_iterate", "ipm_solve", "ipm_solve_linear", "ipm_form_normal_matrix", "ipm_get_factor",
-    "ipm_set_profiling", "ipm_get_phase_ms",
+    "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps",
 ]
 
 IPM_OK = 0
@@ -39,7 +39,7 @@ class IpmError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("eta", C.c_double), ("pivot_guard_eps", C.c_double), ("pivot_guard_big", C.c_double),
-                ("check_every", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int64)]
+                ("check_every", C.c_int32), ("reserved0", C.c_int32), ("sparse_nnz", C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -89,6 +89,7 @@ def load():
     lib.ipm_default_options.argtypes = [C.POINTER(Options)]
     lib.ipm_default_options.restype = None
     lib.ipm_workspace_bytes.argtypes = [i64, i64, C.POINTER(C.c_size_t)]
+    lib.ipm_workspace_bytes_csc.argtypes = [i64, i64, i64, C.POINTER(C.c_size_t)]
     lib.ipm_create.argtypes = [C.c_int, i64, i64, C.POINTER(Options), vp, C.c_size_t, vp, C.POINTER(vp)]
     lib.ipm_destroy.argtypes = [vp]
     lib.ipm_last_error.argtypes = [vp]
@@ -107,6 +108,7 @@ def load():
     lib.ipm_get_factor.argtypes = [vp, pd, i64]
     lib.ipm_set_profiling.argtypes = [vp, C.c_int]
     lib.ipm_get_phase_ms.argtypes = [vp, pd]
+    lib.ipm_debug_get_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("ipm_default_options", "ipm_last_error"):

@@ -18,7 +18,11 @@
 #include "../../include/ipm_hip.h"
 #include "gemm_nt_f64.h"
 #include "potrf_f64.h"
+#include "sparse_ops.h"
 #include "vector_ops.h"
+
+#include <algorithm>
+#include <utility>
 
 using namespace ipm;
 
@@ -45,6 +49,10 @@ struct ipm_handle {
     double *y = nullptr, *b = nullptr, *rb = nullptr, *t1 = nullptr, *t2 = nullptr, *dya = nullptr, *dy = nullptr;
     double *atp = nullptr, *part = nullptr, *slab = nullptr;
     int form_variant = 0;
+    bool sparse = false;                 // A kept as CSR + CSC on the device
+    int64_t nnz_cap = 0, nnz = 0;
+    int *d_rowptr = nullptr, *d_colind = nullptr, *d_colptr = nullptr, *d_rowind = nullptr;
+    double *d_rval = nullptr, *d_cval = nullptr;
     long long* stamp_buf = nullptr;       // diagnostic only (IPM_POTRF_STAMPS=1)
     Scalars* sc = nullptr;
     int* fixed = nullptr;
@@ -82,11 +90,12 @@ struct Layout {
     int64_t mp, np;
     int nblk, rc_chunks, rows_per_chunk, vblk;
     size_t off_A, off_B, off_inv, off_nvec, off_mvec, off_atp, off_part, off_sc, off_fixed, off_slab, total;
+    size_t off_rowptr, off_colind, off_rval, off_colptr, off_rowind, off_cval;
 };
 static const int N_NVEC = 11;   // x s c rc d v q dxa dsa dx ds
 static const int N_MVEC = 7;    // y b rb t1 t2 dya dy
 
-static Layout make_layout(int64_t m, int64_t n) {
+static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     Layout L;
     L.mp = round_up(m, NB);
     L.np = round_up(n, 64);
@@ -100,7 +109,8 @@ static Layout make_layout(int64_t m, int64_t n) {
     L.vblk = (int)(vb < 1 ? 1 : (vb > MAXPART ? MAXPART : vb));
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    L.off_A = take(sizeof(double) * L.mp * L.np);
+    if (sparse_nnz > 0) { L.rc_chunks = 1; L.rows_per_chunk = (int)L.mp; }
+    L.off_A = take(sparse_nnz > 0 ? 0 : sizeof(double) * L.mp * L.np);
     L.off_B = take(sizeof(double) * L.mp * L.mp);
     L.off_inv = take(sizeof(double) * L.nblk * NB * NB);
     L.off_nvec = take(sizeof(double) * L.np * N_NVEC);
@@ -110,6 +120,12 @@ static Layout make_layout(int64_t m, int64_t n) {
     L.off_sc = take(sizeof(Scalars));
     L.off_fixed = take(256);
     L.off_slab = take(sizeof(double) * (size_t)kSlabTiles * 128 * 128);   // split-K partial tiles (64 MB)
+    L.off_rowptr = take(sparse_nnz > 0 ? sizeof(int) * (m + 1) : 0);
+    L.off_colptr = take(sparse_nnz > 0 ? sizeof(int) * (n + 1) : 0);
+    L.off_colind = take(sparse_nnz > 0 ? sizeof(int) * sparse_nnz : 0);
+    L.off_rowind = take(sparse_nnz > 0 ? sizeof(int) * sparse_nnz : 0);
+    L.off_rval = take(sparse_nnz > 0 ? sizeof(double) * sparse_nnz : 0);
+    L.off_cval = take(sparse_nnz > 0 ? sizeof(double) * sparse_nnz : 0);
     L.total = off;
     return L;
 }
@@ -143,6 +159,12 @@ extern "C" int ipm_workspace_bytes(int64_t m, int64_t n, size_t* bytes) {
     return IPM_OK;
 }
 
+extern "C" int ipm_workspace_bytes_csc(int64_t m, int64_t n, int64_t nnz, size_t* bytes) {
+    if (!bytes || m <= 0 || n <= 0 || nnz <= 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "bad arguments to ipm_workspace_bytes_csc");
+    *bytes = make_layout(m, n, nnz).total;
+    return IPM_OK;
+}
+
 // ------------------------------------------------------------------------------- handle
 __global__ void set_params_kernel(Scalars* sc, double e1, double e2, double e3, double eta, int max_iter,
                                   int force, int reset) {
@@ -166,7 +188,10 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.check_every < 1) h->opt.check_every = 1;
     if (!(h->opt.eta > 0.0)) h->opt.eta = 0.91;
     if (!(h->opt.pivot_guard_big > 0.0)) h->opt.pivot_guard_big = 1e64;
-    Layout L = make_layout(m, n);
+    if (h->opt.sparse_nnz < 0) h->opt.sparse_nnz = 0;
+    h->sparse = h->opt.sparse_nnz > 0;
+    h->nnz_cap = h->opt.sparse_nnz;
+    Layout L = make_layout(m, n, h->opt.sparse_nnz);
     h->m = m; h->n = n; h->mp = L.mp; h->np = L.np; h->nblk = L.nblk;
     h->rc_chunks = L.rc_chunks; h->rows_per_chunk = L.rows_per_chunk; h->vblk = L.vblk;
     h->ws_bytes = L.total;
@@ -209,6 +234,9 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->sc = (Scalars*)(base + L.off_sc);
     h->fixed = (int*)(base + L.off_fixed);
     h->slab = (double*)(base + L.off_slab);
+    h->d_rowptr = (int*)(base + L.off_rowptr); h->d_colptr = (int*)(base + L.off_colptr);
+    h->d_colind = (int*)(base + L.off_colind); h->d_rowind = (int*)(base + L.off_rowind);
+    h->d_rval = (double*)(base + L.off_rval); h->d_cval = (double*)(base + L.off_cval);
     if (const char* e = getenv("IPM_FORM_VARIANT")) h->form_variant = atoi(e);
     // zero everything except A and B (padding entries of every vector must stay 0)
     CREATE_TRY(hipMemsetAsync(base + L.off_inv, 0, L.off_slab - L.off_inv, h->stream));
@@ -263,6 +291,7 @@ static bool all_finite(const double* p, int64_t rows, int64_t cols, int64_t ld) 
 
 extern "C" int ipm_set_A_dense(ipm_handle* h, const double* A, int64_t ld, int is_device) {
     if (!h || !A || ld < h->n) return fail(h, IPM_ERR_INVALID_ARG, "ipm_set_A_dense: bad arguments");
+    if (h->sparse) return fail(h, IPM_ERR_STATE, "ipm_set_A_dense: the handle was created for a sparse A (sparse_nnz > 0)");
     HIP_TRY(h, hipSetDevice(h->device));
     if (!is_device && !all_finite(A, h->m, h->n, ld)) return fail(h, IPM_ERR_INVALID_INPUT, "A has non-finite entries");
     HIP_TRY(h, hipMemsetAsync(h->A, 0, sizeof(double) * h->mp * h->np, h->stream));
@@ -277,6 +306,46 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
     if (!h || !colptr || (nnz > 0 && (!rowind || !val)) || nnz < 0) return fail(h, IPM_ERR_INVALID_ARG, "ipm_set_A_csc: bad arguments");
     if (colptr[0] != 0 || colptr[h->n] != nnz) return fail(h, IPM_ERR_INVALID_ARG, "ipm_set_A_csc: colptr does not span nnz");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->sparse) {
+        // canonical CSC (rows sorted, duplicates summed) and its CSR transpose, built on the host
+        std::vector<int> cp(h->n + 1, 0), ri; std::vector<double> cv;
+        ri.reserve((size_t)nnz); cv.reserve((size_t)nnz);
+        std::vector<std::pair<int, double>> col;
+        for (int64_t j = 0; j < h->n; ++j) {
+            if (colptr[j + 1] < colptr[j]) return fail(h, IPM_ERR_INVALID_ARG, "colptr not monotone");
+            col.clear();
+            for (int32_t p = colptr[j]; p < colptr[j + 1]; ++p) {
+                if (rowind[p] < 0 || rowind[p] >= h->m) return fail(h, IPM_ERR_INVALID_ARG, "row index %d out of range", rowind[p]);
+                if (!isfinite(val[p])) return fail(h, IPM_ERR_INVALID_INPUT, "A has non-finite entries");
+                col.emplace_back(rowind[p], val[p]);
+            }
+            std::stable_sort(col.begin(), col.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            for (size_t q = 0; q < col.size(); ++q) {
+                if (!ri.empty() && (int64_t)ri.size() > cp[j] && ri.back() == col[q].first) cv.back() += col[q].second;
+                else { ri.push_back(col[q].first); cv.push_back(col[q].second); }
+            }
+            cp[j + 1] = (int)ri.size();
+        }
+        const int64_t nz = (int64_t)ri.size();
+        if (nz > h->nnz_cap) return fail(h, IPM_ERR_INVALID_ARG, "nnz %lld exceeds the handle's sparse_nnz %lld", (long long)nz, (long long)h->nnz_cap);
+        std::vector<int> rp(h->m + 1, 0), ci((size_t)nz); std::vector<double> rv((size_t)nz);
+        for (int64_t q = 0; q < nz; ++q) rp[ri[q] + 1]++;
+        for (int64_t i = 0; i < h->m; ++i) rp[i + 1] += rp[i];
+        { std::vector<int> next(rp.begin(), rp.end() - 1);
+          for (int64_t j = 0; j < h->n; ++j)
+              for (int q = cp[j]; q < cp[j + 1]; ++q) { int dst = next[ri[q]]++; ci[dst] = (int)j; rv[dst] = cv[q]; } }
+        HIP_TRY(h, hipMemcpyAsync(h->d_colptr, cp.data(), sizeof(int) * (h->n + 1), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_rowptr, rp.data(), sizeof(int) * (h->m + 1), hipMemcpyHostToDevice, h->stream));
+        if (nz > 0) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_rowind, ri.data(), sizeof(int) * nz, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_cval, cv.data(), sizeof(double) * nz, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_colind, ci.data(), sizeof(int) * nz, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_rval, rv.data(), sizeof(double) * nz, hipMemcpyHostToDevice, h->stream));
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->nnz = nz; h->haveA = true; h->predictor_valid = false;
+        return IPM_OK;
+    }
     // dense row-major image of A (scattered on the host, one upload)
     double* img = (double*)calloc((size_t)h->mp * h->np, sizeof(double));
     if (!img) return fail(h, IPM_ERR_INVALID_ARG, "ipm_set_A_csc: host allocation of %lld x %lld failed", (long long)h->mp, (long long)h->np);
@@ -362,11 +431,29 @@ static VecArgs vec_args(ipm_handle* h) {
     return a;
 }
 
+static SparseA sparse_view(const ipm_handle* h) {
+    SparseA A;
+    A.rowptr = h->d_rowptr; A.colind = h->d_colind; A.rval = h->d_rval;
+    A.colptr = h->d_colptr; A.rowind = h->d_rowind; A.cval = h->d_cval;
+    A.m = (int)h->m; A.n = (int)h->n;
+    return A;
+}
+
 static void launch_gemv_n(ipm_handle* h, const double* v, double sa, double sb, const double* add, double* out) {
+    if (h->sparse) {
+        hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)((h->mp + 15) / 16)), dim3(256), 0, h->stream, sparse_view(h),
+                           (int)h->mp, v, sa, sb, add, out, &h->sc->done);
+        return;
+    }
     hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)(h->mp / 4)), dim3(256), 0, h->stream, h->A, h->np, (int)h->mp,
                        (int)h->np, v, sa, sb, add, out, &h->sc->done);
 }
 static void launch_gemv_t(ipm_handle* h, const double* u) {
+    if (h->sparse) {
+        hipLaunchKernelGGL(spmv_csc_t_kernel, dim3((unsigned)((h->np + 15) / 16)), dim3(256), 0, h->stream, sparse_view(h),
+                           (int)h->np, u, h->atp, &h->sc->done);
+        return;
+    }
     dim3 grid((unsigned)((h->np + 511) / 512), (unsigned)h->rc_chunks);
     hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->A, h->np, h->rows_per_chunk, (int)h->np, u,
                        h->atp, &h->sc->done);
@@ -385,6 +472,22 @@ static int enqueue_residuals(ipm_handle* h) {
 
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
 static int enqueue_form(ipm_handle* h, const double* d) {
+    if (h->sparse) {
+        if (h->mp <= SP_LDS_MAX_MP) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(h, hipFuncSetAttribute((const void*)adat_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(adat_sparse_kernel, dim3((unsigned)h->mp), dim3(256), (size_t)h->mp * sizeof(double), h->stream,
+                               sparse_view(h), d, h->B, h->mp, (int)h->mp, &h->sc->done);
+        } else {
+            hipLaunchKernelGGL(adat_sparse_global_kernel, dim3((unsigned)h->mp), dim3(256), 0, h->stream, sparse_view(h), d,
+                               h->B, h->mp, (int)h->mp, &h->sc->done);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
     GemmNT g;
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;

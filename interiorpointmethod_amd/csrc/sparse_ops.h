@@ -1,0 +1,118 @@
+// sparse_ops.h -- sparse-A front end of the hot path for the Netlib instances (gfx950).
+//
+// The reference keeps A as a scipy CSC matrix (sparse_interior.py:215) and forms
+// B = A @ D_square @ A.T with two SpGEMMs (main.py:223-224), then A @ v / A.T @ y SpMVs
+// (main.py:66-73, 225, 227).  Here A lives on the device in BOTH CSR and CSC form (built
+// once at upload); B is still the dense m x m matrix the blocked Cholesky factors, because
+// the Cholesky fill of these normal matrices is near dense -- only its
+// formation is sparse:  B[i][k] = sum_j a_ij d_j a_kj  costs sum_j nnz(A[:,j])^2 multiply-adds
+// instead of m^2 n (STOCFOR3: 4.5e5 instead of 6.5e12).
+//
+// One workgroup owns one row of B (no atomics, fixed summation order => bitwise
+// reproducible): it walks the nonzeros (i,j) of its row of A in CSR order and, for each,
+// scatters a_ij d_j * A[:,j] (CSC column) into an LDS accumulator of length mp, then streams
+// the finished row to HBM with coalesced 16-byte stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_nt_f64.h"
+
+namespace ipm {
+
+struct SparseA {
+    const int* rowptr; const int* colind; const double* rval;    // CSR
+    const int* colptr; const int* rowind; const double* cval;    // CSC
+    int m, n;
+};
+
+constexpr int SP_LDS_MAX_MP = 19456;      // 152 KB accumulator row fits the 160 KB LDS
+
+// B[row][:] = sum_j a_rj d_j A[:,j]^T  for row < m; padding rows get e_row.  grid = mp workgroups.
+__global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const double* __restrict__ d, double* B,
+                                                          int64_t ldb, int mp, const int* done) {
+    if (done && *done) return;
+    extern __shared__ __attribute__((aligned(16))) double acc[];          // mp doubles
+    const int row = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < mp; k += 256) acc[k] = 0.0;
+    __syncthreads();
+    if (row < A.m) {
+        const int pb = A.rowptr[row], pe = A.rowptr[row + 1];
+        for (int p = pb; p < pe; ++p) {                 // sequential over the row's nonzeros: fixed order
+            const int j = A.colind[p];
+            const double coef = A.rval[p] * d[j];
+            const int qb = A.colptr[j], qe = A.colptr[j + 1];
+            for (int q = qb + tid; q < qe; q += 256)    // distinct row indices within one column: no collisions
+                acc[A.rowind[q]] += coef * A.cval[q];
+            __syncthreads();
+        }
+    } else if (tid == 0) {
+        acc[row] = 1.0;
+    }
+    __syncthreads();
+    double* out = B + (int64_t)row * ldb;
+    for (int k = tid * 2; k < mp; k += 512)
+        *reinterpret_cast<f64x2*>(out + k) = (f64x2){acc[k], acc[k + 1]};
+}
+
+// Same contract with the accumulator row in HBM (mp too large for LDS): the owning workgroup zeroes
+// its row of B, then accumulates in place; __syncthreads() orders the read-modify-writes of one CU.
+__global__ __launch_bounds__(256) void adat_sparse_global_kernel(SparseA A, const double* __restrict__ d, double* B,
+                                                                 int64_t ldb, int mp, const int* done) {
+    if (done && *done) return;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    double* out = B + (int64_t)row * ldb;
+    for (int k = tid; k < mp; k += 256) out[k] = (row >= A.m && k == row) ? 1.0 : 0.0;
+    __syncthreads();
+    if (row >= A.m) return;
+    const int pb = A.rowptr[row], pe = A.rowptr[row + 1];
+    for (int p = pb; p < pe; ++p) {
+        const int j = A.colind[p];
+        const double coef = A.rval[p] * d[j];
+        const int qb = A.colptr[j], qe = A.colptr[j + 1];
+        for (int q = qb + tid; q < qe; q += 256) out[A.rowind[q]] += coef * A.cval[q];
+        __syncthreads();
+    }
+}
+
+// out[i] = sa * (A[i,:] . v) + sb * add[i]  (CSR; 16 lanes per row, fixed-order tree reduction);
+// rows m..mp-1 (padding) get sb * add[i].
+__global__ __launch_bounds__(256) void spmv_csr_kernel(SparseA A, int mp, const double* __restrict__ v, double sa,
+                                                       double sb, const double* __restrict__ add, double* out,
+                                                       const int* done) {
+    if (done && *done) return;
+    const int l16 = threadIdx.x & 15;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= mp) return;
+    double s = 0.0;
+    if (row < A.m) {
+        const int pb = A.rowptr[row], pe = A.rowptr[row + 1];
+        for (int p = pb + l16; p < pe; p += 16) s += A.rval[p] * v[A.colind[p]];
+    }
+    s += __shfl_xor(s, 8, 16);
+    s += __shfl_xor(s, 4, 16);
+    s += __shfl_xor(s, 2, 16);
+    s += __shfl_xor(s, 1, 16);
+    if (l16 == 0) out[row] = sa * s + (add ? sb * add[row] : 0.0);
+}
+
+// w[j] = A[:,j] . u  (CSC; 16 lanes per column).  Written to w[0..np): the vector kernels read it as
+// the single "row chunk" of the dense GEMV-T partial buffer.
+__global__ __launch_bounds__(256) void spmv_csc_t_kernel(SparseA A, int np, const double* __restrict__ u, double* w,
+                                                         const int* done) {
+    if (done && *done) return;
+    const int l16 = threadIdx.x & 15;
+    const int col = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (col >= np) return;
+    double s = 0.0;
+    if (col < A.n) {
+        const int pb = A.colptr[col], pe = A.colptr[col + 1];
+        for (int p = pb + l16; p < pe; p += 16) s += A.cval[p] * u[A.rowind[p]];
+    }
+    s += __shfl_xor(s, 8, 16);
+    s += __shfl_xor(s, 4, 16);
+    s += __shfl_xor(s, 2, 16);
+    s += __shfl_xor(s, 1, 16);
+    if (l16 == 0) w[col] = s;
+}
+
+}  // namespace ipm

@@ -45,14 +45,17 @@ class IpmSolver:
     """One LP bound to one GPU: owns a libipm_hip handle whose workspace is a torch tensor."""
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
-                 check_every=4, use_torch=True):
+                 check_every=4, use_torch=True, dense=False):
         lib = _lib.load()
         self._lib = lib
         self._h = None
         if _sp is not None and _sp.issparse(A):
             A = _sp.csc_matrix(A, dtype=np.float64)
             A.sum_duplicates()
+            A.sort_indices()
             m, n = A.shape
+            if dense or A.nnz == 0:
+                A = np.ascontiguousarray(A.toarray())
         else:
             A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
             if A.ndim != 2:
@@ -66,7 +69,12 @@ class IpmSolver:
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
         opts.check_every = int(check_every)
         nbytes = C.c_size_t(0)
-        _lib.check(None, lib.ipm_workspace_bytes(self.m, self.n, C.byref(nbytes)))
+        self.sparse = _sp is not None and _sp.issparse(A)
+        if self.sparse:                      # A stays sparse on the device (CSR + CSC, sparse formation of B)
+            opts.sparse_nnz = int(A.nnz)
+            _lib.check(None, lib.ipm_workspace_bytes_csc(self.m, self.n, int(A.nnz), C.byref(nbytes)))
+        else:
+            _lib.check(None, lib.ipm_workspace_bytes(self.m, self.n, C.byref(nbytes)))
         self.workspace_bytes = nbytes.value
         ws_ptr, stream = None, None
         self._ws = None
@@ -82,7 +90,7 @@ class IpmSolver:
         _lib.check(None, lib.ipm_create(int(device), self.m, self.n, C.byref(opts), ws_ptr,
                                         self.workspace_bytes if ws_ptr else 0, stream, C.byref(h)))
         self._h = h
-        if _sp is not None and _sp.issparse(A):
+        if self.sparse:
             indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
             indices = np.ascontiguousarray(A.indices, dtype=np.int32)
             data = np.ascontiguousarray(A.data, dtype=np.float64)

@@ -99,7 +99,7 @@ def netlib_main(args):
     t0 = time.perf_counter()
     rec, _ = batch.run_batch(probs, costs=costs, device=local_rank, dist=dist,
                              gather_device=torch.device("cuda", local_rank) if dist is not None else None,
-                             tol=1e-8, max_iter=300)
+                             tol=1e-8, max_iter=300, regularize=args.regularize)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -116,7 +116,7 @@ def netlib_main(args):
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
                "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s), 1 LP per GPU at a time" % (
                    args.netlib_set, len(names), max(world, 1))},
-               "summary": summ, "wall_seconds": elapsed,
+               "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize,
                "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
                           for r in rec}}
         print(json.dumps(out))
@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--netlib-set", default="all", choices=["all", "parity"],
                     help="all 73 valid files, or the 26 on which the reference converges")
     ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
+    ap.add_argument("--regularize", type=float, default=0.0, help="netlib: Tikhonov shift (0 = reference-faithful)")
     args = ap.parse_args()
     if args.workload == "netlib":
         return netlib_main(args)
@@ -202,6 +203,13 @@ def main():
         form_ms = phases[0] / K
         flops_form = float(m) * m * n                       # lower-triangle SYRK, SURVEY 8(d)
         achieved = flops_form / (form_ms * 1e-3) / 1e12 if form_ms > 0 else 0.0
+        traffic = None          # HBM bytes per launch of the dominant kernel: PMC pass collected separately
+        try:                    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_form_kernel.json)
+            if (m, n) == (M_DEFAULT, N_DEFAULT):
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_form_kernel.json")) as fh:
+                    traffic = json.load(fh)["derived"]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "IPM iterations/sec (m=%d,n=%d dense LP)" % (m, n),
             "value": its_per_s, "unit": "iterations/s", "n_gpus": ngpu, "steps": K, "warmup": args.warmup,
@@ -211,7 +219,7 @@ def main():
                                    "(BASELINE.json configs[1]); replicas per GPU" % (m, n),
                        "reset_every": RESET_EVERY},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "kernel": "gemm_nt_f64_kernel<128,128,16,2,2> (B = A diag(d) A^T)",
                          "flops_per_launch": flops_form, "avg_launch_ms": form_ms},
             "phases_ms_per_step": {"form": form_ms, "factor": phases[1] / K, "trisolve": phases[2] / K,

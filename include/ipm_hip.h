@@ -60,6 +60,8 @@ typedef struct ipm_options {
     int32_t reserved0;
     int64_t sparse_nnz;      /* > 0: handle keeps A sparse (CSR+CSC on the device, no dense image) with at
                                 most this many nonzeros; only ipm_set_A_csc may then supply A */
+    double regularize;       /* Tikhonov shift: factor B + regularize*max diag(B)*I (0 = off, the default;
+                                1e-12 makes the rank-deficient QAP family converge) */
 } ipm_options;
 
 /* per-solve statistics; norms use the reference's scaling (main.py:170-171) */

@@ -39,7 +39,8 @@ class IpmError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("eta", C.c_double), ("pivot_guard_eps", C.c_double), ("pivot_guard_big", C.c_double),
-                ("check_every", C.c_int32), ("reserved0", C.c_int32), ("sparse_nnz", C.c_int64)]
+                ("check_every", C.c_int32), ("reserved0", C.c_int32), ("sparse_nnz", C.c_int64),
+                ("regularize", C.c_double)]
 
 
 class Stats(C.Structure):

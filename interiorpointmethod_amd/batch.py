@@ -40,14 +40,15 @@ def lpt_partition(costs, world):
     return shards
 
 
-def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0):
+def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0):
     """Solve one LP (A, b, c) on `device` with the HIP path -> dict of statistics."""
     from . import _lib
     from .solver import solve_with_info
     A, b, c = problem
     t0 = time.perf_counter()
     try:
-        _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device)
+        _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device,
+                                        regularize=regularize)
         info = dict(info)
     except _lib.IpmError as e:
         nan = float("nan")

@@ -46,6 +46,7 @@ struct GemmNT {
     int n_direct, split_p, chunk_stages;
     double* slab;
     int tile_offset;            // logical tile = tile_offset + index (used to skip the first lower tile)
+    const int* tile_order;      // optional: logical tile -> (ti << 16 | tj), a 2-D patch order for L2 reuse
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -98,7 +99,10 @@ void gemm_nt_f64_kernel(GemmNT g) {
             kend = min(kend, kbeg + g.chunk_stages);
             slab_out = g.slab + (size_t)r * (BM * BN);
         }
-        if (g.lower) {
+        if (g.tile_order) {
+            int packed = g.tile_order[bid];
+            ti = packed >> 16; tj = packed & 0xffff;
+        } else if (g.lower) {
             // bid -> (ti, tj), ti >= tj, row-major enumeration of the lower triangle
             int t = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
             while ((t + 1) * (t + 2) / 2 <= bid) ++t;
@@ -230,7 +234,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmNT g) {
     if (g.done && *g.done) return;
     const int tile = g.n_direct + blockIdx.y;
     int ti, tj;
-    if (g.lower) {
+    if (g.tile_order) {
+        int packed = g.tile_order[tile];
+        ti = packed >> 16; tj = packed & 0xffff;
+    } else if (g.lower) {
         int t = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
         while ((t + 1) * (t + 2) / 2 <= tile) ++t;
         while (t * (t + 1) / 2 > tile) --t;

@@ -36,6 +36,9 @@ struct ipm_handle {
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
+    int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
+                                          // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
+    unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
     int64_t m = 0, n = 0, mp = 0, np = 0;
     int nblk = 0, rc_chunks = 0, rows_per_chunk = 0, vblk = 0;
     ipm_options opt;
@@ -51,6 +54,7 @@ struct ipm_handle {
     int form_variant = 0;
     bool sparse = false;                 // A kept as CSR + CSC on the device
     int64_t nnz_cap = 0, nnz = 0;
+    int* d_tile_order = nullptr;         // 2-D patch order of the lower 128x128 tiles of B (L2 reuse)
     int *d_rowptr = nullptr, *d_colind = nullptr, *d_colptr = nullptr, *d_rowind = nullptr;
     double *d_rval = nullptr, *d_cval = nullptr;
     long long* stamp_buf = nullptr;       // diagnostic only (IPM_POTRF_STAMPS=1)
@@ -90,7 +94,7 @@ struct Layout {
     int64_t mp, np;
     int nblk, rc_chunks, rows_per_chunk, vblk;
     size_t off_A, off_B, off_inv, off_nvec, off_mvec, off_atp, off_part, off_sc, off_fixed, off_slab, total;
-    size_t off_rowptr, off_colind, off_rval, off_colptr, off_rowind, off_cval;
+    size_t off_rowptr, off_colind, off_rval, off_colptr, off_rowind, off_cval, off_order;
 };
 static const int N_NVEC = 11;   // x s c rc d v q dxa dsa dx ds
 static const int N_MVEC = 7;    // y b rb t1 t2 dya dy
@@ -120,6 +124,7 @@ static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     L.off_sc = take(sizeof(Scalars));
     L.off_fixed = take(256);
     L.off_slab = take(sizeof(double) * (size_t)kSlabTiles * 128 * 128);   // split-K partial tiles (64 MB)
+    L.off_order = take(sizeof(int) * ((size_t)L.nblk * (L.nblk + 1) / 2));
     L.off_rowptr = take(sparse_nnz > 0 ? sizeof(int) * (m + 1) : 0);
     L.off_colptr = take(sparse_nnz > 0 ? sizeof(int) * (n + 1) : 0);
     L.off_colind = take(sparse_nnz > 0 ? sizeof(int) * sparse_nnz : 0);
@@ -188,6 +193,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.check_every < 1) h->opt.check_every = 1;
     if (!(h->opt.eta > 0.0)) h->opt.eta = 0.91;
     if (!(h->opt.pivot_guard_big > 0.0)) h->opt.pivot_guard_big = 1e64;
+    if (!(h->opt.regularize >= 0.0)) h->opt.regularize = 0.0;
     if (h->opt.sparse_nnz < 0) h->opt.sparse_nnz = 0;
     h->sparse = h->opt.sparse_nnz > 0;
     h->nnz_cap = h->opt.sparse_nnz;
@@ -234,6 +240,19 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->sc = (Scalars*)(base + L.off_sc);
     h->fixed = (int*)(base + L.off_fixed);
     h->slab = (double*)(base + L.off_slab);
+    h->d_tile_order = (int*)(base + L.off_order);
+    {   // lower tiles enumerated super-block by super-block (8 x 8 tiles): the ~64 workgroups an XCD runs
+        // at once then share 8 + 8 operand panels in that XCD's L2 instead of 1 + 64
+        std::vector<int> order;
+        const int nT = L.nblk, PB = 8;
+        order.reserve((size_t)nT * (nT + 1) / 2);
+        for (int I = 0; I * PB < nT; ++I)
+            for (int J = 0; J <= I; ++J)
+                for (int ti = I * PB; ti < nT && ti < (I + 1) * PB; ++ti)
+                    for (int tj = J * PB; tj <= ti && tj < (J + 1) * PB; ++tj) order.push_back((ti << 16) | tj);
+        CREATE_TRY(hipMemcpyAsync(h->d_tile_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream));
+    }
     h->d_rowptr = (int*)(base + L.off_rowptr); h->d_colptr = (int*)(base + L.off_colptr);
     h->d_colind = (int*)(base + L.off_colind); h->d_rowind = (int*)(base + L.off_rowind);
     h->d_rval = (double*)(base + L.off_rval); h->d_cval = (double*)(base + L.off_cval);
@@ -245,6 +264,9 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
+    if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
+    CREATE_TRY(hipMalloc((void**)&h->d_flags, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
+    CREATE_TRY(hipMemset(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 4 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 4 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -275,6 +297,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) (void)hipHostFree(h->h_sc);
     if (h->stamp_buf) (void)hipFree(h->stamp_buf);
+    if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -489,6 +512,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
         return IPM_OK;
     }
     GemmNT g;
+    g.tile_order = h->d_tile_order;
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;
     g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = (int)h->m; g.done = &h->sc->done;
@@ -518,7 +542,7 @@ static int enqueue_factor(ipm_handle* h) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
         pd.inv = h->invD + (int64_t)k * NB * NB;
-        pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big;
+        pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->opt.regularize;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
@@ -530,10 +554,12 @@ static int enqueue_factor(ipm_handle* h) {
         if (rem <= 0) break;
         double* panel = h->B + (int64_t)(k + 1) * NB * h->mp + (int64_t)k * NB;
         GemmNT t;                                                   // L_ik = B_ik inv(L_kk)^T, in place
+        t.tile_order = nullptr;
         t.P = panel; t.ldp = h->mp; t.Q = pd.inv; t.ldq = NB; t.w = nullptr;
         t.C = panel; t.ldc = h->mp; t.M = rem; t.N = NB; t.K = NB;
         t.alpha = 1.0; t.beta = 0.0; t.lower = 0; t.unit_diag_from = -1; t.done = done;
         GemmNT u;                                                   // B_ij -= L_ik L_jk^T
+        u.tile_order = nullptr;
         u.P = panel; u.ldp = h->mp; u.Q = panel; u.ldq = h->mp; u.w = nullptr;
         u.C = h->B + (int64_t)(k + 1) * NB * (h->mp + 1); u.ldc = h->mp; u.M = rem; u.N = rem; u.K = NB;
         u.alpha = -1.0; u.beta = 1.0; u.lower = 1; u.unit_diag_from = -1; u.done = done;
@@ -565,6 +591,19 @@ static int enqueue_factor(ipm_handle* h) {
 
 // out = B^{-1} r  (r is consumed; uses t2 as the intermediate)
 static int enqueue_potrs(ipm_handle* h, double* r, double* out) {
+    if (h->persistent_trsv && h->nblk >= 2 && h->nblk <= 240) {
+        // flags: [0,nblk) forward, [nblk,2nblk) backward, then the timeout word; zeroed per call
+        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk), h->stream));
+        TrsvPersist p;
+        p.L = h->B; p.ld = h->mp; p.inv = h->invD; p.nblk = h->nblk; p.done = &h->sc->done;
+        p.timeout = h->d_flags + 2 * (size_t)h->nblk;
+        p.rhs = r; p.z = h->t2; p.flags = h->d_flags;
+        hipLaunchKernelGGL(trsv_fwd_persistent_kernel, dim3(h->nblk), dim3(256), 0, h->stream, p);
+        p.rhs = h->t2; p.z = out; p.flags = h->d_flags + h->nblk;
+        hipLaunchKernelGGL(trsv_bwd_persistent_kernel, dim3(h->nblk), dim3(256), 0, h->stream, p);
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
     TrsvStep a;
     a.L = h->B; a.ld = h->mp; a.inv = h->invD; a.done = &h->sc->done;
     a.r = r; a.z = h->t2;
@@ -637,8 +676,11 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
 }
 
 static int read_scalars(ipm_handle* h) {
+    unsigned tmo = 0;
     HIP_TRY(h, hipMemcpyAsync(h->h_sc, h->sc, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&tmo, h->d_flags + 2 * (size_t)h->nblk, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (tmo) return fail(h, IPM_ERR_HIP, "persistent triangular solve timed out waiting for a hand-off (workgroups not co-resident?)");
     return IPM_OK;
 }
 

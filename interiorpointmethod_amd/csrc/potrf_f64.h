@@ -40,6 +40,7 @@ struct PotrfDiag {
     double* inv;                 // out: inv(L_kk), dense 128 x 128 row-major, zeros above diag
     const double* maxdiag;       // device scalar: max diag of the unfactored B
     double eps, big;
+    double shift_rel;            // Tikhonov shift relative to max diag(B), added to the diagonal at load
     int* fixed;                  // device counter of guarded pivots (accumulates)
     const int* done;
     long long* stamps;           // diagnostic build only (STAMP = true): s_memtime per phase and wave
@@ -254,6 +255,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
             if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
     }
+    if (a.shift_rel != 0.0) {
+        __syncthreads();
+        if (tid < NB) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
+    }
     __syncthreads();
     IPM_STAMP(1);
 
@@ -360,29 +365,32 @@ __global__ __launch_bounds__(256) void maxdiag_kernel(const double* B, int64_t l
 // Sums are in a fixed order: results are bitwise reproducible.
 // ------------------------------------------------------------------------------------------
 
-// y[128] = M[128x128] * v  (M row-major, ldm) -- all 256 threads; v in LDS; result in LDS `out`.
-__device__ __forceinline__ void block_gemv_n(const double* __restrict__ M, int64_t ldm,
-                                             const double* vs, double* out) {
-    const int tid = threadIdx.x;
-    const int l16 = tid & 15, rg = tid >> 4;          // 16 lanes per row, 16 rows per pass
-    double v[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { v[2 * q] = vs[(l16 + 16 * q) * 2]; v[2 * q + 1] = vs[(l16 + 16 * q) * 2 + 1]; }
-    double part[8];
+// A 128 x 128 row-major block held in the registers of one 256-thread workgroup: thread
+// (rg = tid>>4, l16 = tid&15) keeps, for each of the 8 passes p, the four 16-byte chunks
+// l16, l16+16, l16+32, l16+48 of row 16p+rg (so one load instruction of a wave covers four full rows).
+struct BlockRegs { f64x2 m[8][4]; };
+
+__device__ __forceinline__ void block_load(BlockRegs& R, const double* __restrict__ M, int64_t ldm) {
+    const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const double* row = M + (int64_t)(p * 16 + rg) * ldm;
-        double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f64x2 m2 = *reinterpret_cast<const f64x2*>(row + (l16 + 16 * q) * 2);
-            acc += m2.x * v[2 * q] + m2.y * v[2 * q + 1];
-        }
-        part[p] = acc;
+        for (int q = 0; q < 4; ++q) R.m[p][q] = *reinterpret_cast<const f64x2*>(row + (l16 + 16 * q) * 2);
     }
+}
+
+// out[128] = M v   (v, out in LDS; fixed-order 16-lane tree reduction)
+__device__ __forceinline__ void block_gemv_n(const BlockRegs& R, const double* vs, double* out) {
+    const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = vs[(l16 + 16 * q) * 2]; v[2 * q + 1] = vs[(l16 + 16 * q) * 2 + 1]; }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-        double s = part[p];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += R.m[p][q].x * v[2 * q] + R.m[p][q].y * v[2 * q + 1];
         s += __shfl_xor(s, 8, 16);
         s += __shfl_xor(s, 4, 16);
         s += __shfl_xor(s, 2, 16);
@@ -391,10 +399,8 @@ __device__ __forceinline__ void block_gemv_n(const double* __restrict__ M, int64
     }
 }
 
-// y[128] = M^T * v  (y[c] = sum_r M[r][c] v[r]) -- all 256 threads; v in LDS; result in LDS `out`;
-// `scratch` is 16*128 doubles of LDS.
-__device__ __forceinline__ void block_gemv_t(const double* __restrict__ M, int64_t ldm,
-                                             const double* vs, double* out, double* scratch) {
+// out[128] = M^T v  (v, out in LDS; `scratch` = 16*128 doubles of LDS; contains two barriers)
+__device__ __forceinline__ void block_gemv_t(const BlockRegs& R, const double* vs, double* out, double* scratch) {
     const int tid = threadIdx.x;
     const int l16 = tid & 15, rg = tid >> 4;
     double acc[8];
@@ -402,21 +408,16 @@ __device__ __forceinline__ void block_gemv_t(const double* __restrict__ M, int64
     for (int q = 0; q < 8; ++q) acc[q] = 0.0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-        const int r = p * 16 + rg;
-        const double* row = M + (int64_t)r * ldm;
-        const double vr = vs[r];
+        const double vr = vs[p * 16 + rg];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f64x2 m2 = *reinterpret_cast<const f64x2*>(row + (l16 + 16 * q) * 2);
-            acc[2 * q] += m2.x * vr;
-            acc[2 * q + 1] += m2.y * vr;
+            acc[2 * q] += R.m[p][q].x * vr;
+            acc[2 * q + 1] += R.m[p][q].y * vr;
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        scratch[rg * NB + (l16 + 16 * q) * 2] = acc[2 * q];
-        scratch[rg * NB + (l16 + 16 * q) * 2 + 1] = acc[2 * q + 1];
-    }
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f64x2*>(&scratch[rg * NB + (l16 + 16 * q) * 2]) = (f64x2){acc[2 * q], acc[2 * q + 1]};
     __syncthreads();
     if (tid < NB) {
         double s = 0.0;
@@ -437,20 +438,25 @@ struct TrsvStep {
 };
 
 // forward step k: z_k = inv(L_kk) r_k ; r_i -= L_ik z_k for i > k.  grid = nblk - k.
+// Both 128 x 128 blocks are fetched into registers up front, so the second product does not pay a
+// second memory latency after z_k is known.
 __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(TrsvStep a) {
     if (a.done && *a.done) return;
     __shared__ double vs[NB], zs[NB], us[NB];
     const int tid = threadIdx.x;
     const int i = a.k + blockIdx.x;
+    BlockRegs RI, RL;
+    block_load(RI, a.inv + (int64_t)a.k * NB * NB, NB);
+    if (blockIdx.x != 0) block_load(RL, a.L + (int64_t)i * NB * a.ld + (int64_t)a.k * NB, a.ld);
     if (tid < NB) vs[tid] = a.r[(int64_t)a.k * NB + tid];
     __syncthreads();
-    block_gemv_n(a.inv + (int64_t)a.k * NB * NB, NB, vs, zs);
+    block_gemv_n(RI, vs, zs);
     __syncthreads();
     if (blockIdx.x == 0) {
         if (tid < NB) a.z[(int64_t)a.k * NB + tid] = zs[tid];
         return;
     }
-    block_gemv_n(a.L + (int64_t)i * NB * a.ld + (int64_t)a.k * NB, a.ld, zs, us);
+    block_gemv_n(RL, zs, us);
     __syncthreads();
     if (tid < NB) a.r[(int64_t)i * NB + tid] -= us[tid];
 }
@@ -460,18 +466,136 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(TrsvStep a) {
 __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) {
     if (a.done && *a.done) return;
     __shared__ double vs[NB], ws[NB], us[NB];
-    __shared__ double scratch[16 * NB];
+    __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
     const int tid = threadIdx.x;
     const int j = blockIdx.x;
+    BlockRegs RI, RL;
+    block_load(RI, a.inv + (int64_t)a.k * NB * NB, NB);
+    if (j != a.k) block_load(RL, a.L + (int64_t)a.k * NB * a.ld + (int64_t)j * NB, a.ld);
     if (tid < NB) vs[tid] = a.r[(int64_t)a.k * NB + tid];
     __syncthreads();
-    block_gemv_t(a.inv + (int64_t)a.k * NB * NB, NB, vs, ws, scratch);
+    block_gemv_t(RI, vs, ws, scratch);
     if (j == a.k) {
         if (tid < NB) a.z[(int64_t)a.k * NB + tid] = ws[tid];
         return;
     }
-    block_gemv_t(a.L + (int64_t)a.k * NB * a.ld + (int64_t)j * NB, a.ld, ws, us, scratch);
+    block_gemv_t(RL, ws, us, scratch);
     if (tid < NB) a.r[(int64_t)j * NB + tid] -= us[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent triangular solves: ONE launch per substitution instead of one per block step.
+// Workgroup i owns block row i (forward) / block column j (backward); it consumes the solution
+// blocks z_k of the earlier steps as they are published and publishes its own.  Off the critical
+// path every workgroup streams its own 128 x 128 tiles (next tile prefetched into registers while
+// it waits), so a step costs one hand-off plus two register-resident block products instead of
+// a kernel boundary plus two dependent memory latencies.
+//
+// Hand-off (placement independent, cdna guide G16 "8-byte agent atomics both sides"): the
+// producer stores z_k with relaxed agent-scope atomic stores (write-through), every storing wave
+// drains vmcnt, the workgroup barriers, then ONE lane stores the flag (relaxed, agent).  The
+// consumer polls that one word from one lane (bounded spin, s_sleep), barriers, and reads z_k
+// with relaxed agent-scope atomic loads (L1 bypass).  Flags are zeroed by a memset node before
+// every launch; epoch = 1.  Requires all nblk workgroups resident (nblk <= 256, 1 per CU) --
+// the launcher falls back to the per-step kernels otherwise.  A spin that exceeds its bound
+// sets *timeout and the workgroup gives up (results invalid, no hang).
+// ------------------------------------------------------------------------------------------
+struct TrsvPersist {
+    const double* L; int64_t ld;
+    const double* inv;
+    const double* rhs;               // input right-hand side (not modified)
+    double* z;                       // solution blocks (published through agent-scope atomics)
+    unsigned* flags;                 // [nblk], zeroed before the launch
+    unsigned* timeout;               // set to 1 when a spin gave up
+    int nblk;
+    const int* done;
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+typedef __attribute__((address_space(1))) double gf64_t;
+
+__device__ __forceinline__ bool wait_flag(unsigned* flag, unsigned* timeout) {
+    // one lane polls; returns false on timeout (wave-uniform through LDS by the caller)
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+    return true;
+}
+
+// forward: L z = rhs.  grid = nblk, block = 256.
+__global__ __launch_bounds__(256) void trsv_fwd_persistent_kernel(TrsvPersist a) {
+    if (a.done && *a.done) return;
+    __shared__ double acc[NB], zk[NB], us[NB];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x;
+    BlockRegs RI, RA, RB;
+    block_load(RI, a.inv + (int64_t)i * NB * NB, NB);
+    if (i > 0) block_load(RA, a.L + (int64_t)i * NB * a.ld, a.ld);
+    if (tid < NB) acc[tid] = a.rhs[(int64_t)i * NB + tid];
+    if (tid == 0) ok_s = 1;
+    __syncthreads();
+    for (int k = 0; k < i; ++k) {
+        // prefetch the next tile of this block row while waiting for z_k
+        if (k + 1 < i) {
+            if (k & 1) block_load(RA, a.L + (int64_t)i * NB * a.ld + (int64_t)(k + 1) * NB, a.ld);
+            else block_load(RB, a.L + (int64_t)i * NB * a.ld + (int64_t)(k + 1) * NB, a.ld);
+        }
+        if (tid == 0 && !wait_flag(a.flags + k, a.timeout)) ok_s = 0;
+        __syncthreads();
+        if (!ok_s) return;
+        if (tid < NB) zk[tid] = __hip_atomic_load(a.z + (int64_t)k * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (k & 1) block_gemv_n(RB, zk, us); else block_gemv_n(RA, zk, us);
+        __syncthreads();
+        if (tid < NB) acc[tid] -= us[tid];
+        __syncthreads();
+    }
+    block_gemv_n(RI, acc, us);
+    __syncthreads();
+    if (tid < NB) __hip_atomic_store(a.z + (int64_t)i * NB + tid, us[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.flags + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// backward: L^T w = rhs.  Workgroup b owns block column j = nblk-1-b (so the first-dispatched
+// workgroups are the first on the dependency chain).
+__global__ __launch_bounds__(256) void trsv_bwd_persistent_kernel(TrsvPersist a) {
+    if (a.done && *a.done) return;
+    __shared__ double acc[NB], wk[NB], us[NB];
+    __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x;
+    const int j = a.nblk - 1 - (int)blockIdx.x;
+    BlockRegs RI, RA, RB;
+    block_load(RI, a.inv + (int64_t)j * NB * NB, NB);
+    const int last = a.nblk - 1;
+    if (j < last) block_load(RA, a.L + (int64_t)last * NB * a.ld + (int64_t)j * NB, a.ld);
+    if (tid < NB) acc[tid] = __hip_atomic_load(a.rhs + (int64_t)j * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) ok_s = 1;
+    __syncthreads();
+    for (int k = last, it = 0; k > j; --k, ++it) {
+        if (k - 1 > j) {
+            if (it & 1) block_load(RA, a.L + (int64_t)(k - 1) * NB * a.ld + (int64_t)j * NB, a.ld);
+            else block_load(RB, a.L + (int64_t)(k - 1) * NB * a.ld + (int64_t)j * NB, a.ld);
+        }
+        if (tid == 0 && !wait_flag(a.flags + k, a.timeout)) ok_s = 0;
+        __syncthreads();
+        if (!ok_s) return;
+        if (tid < NB) wk[tid] = __hip_atomic_load(a.z + (int64_t)k * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (it & 1) block_gemv_t(RB, wk, us, scratch); else block_gemv_t(RA, wk, us, scratch);
+        if (tid < NB) acc[tid] -= us[tid];
+        __syncthreads();
+    }
+    block_gemv_t(RI, acc, us, scratch);
+    if (tid < NB) __hip_atomic_store(a.z + (int64_t)j * NB + tid, us[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.flags + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ipm

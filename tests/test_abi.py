@@ -43,7 +43,7 @@ def test_abi_version_and_host_only_calls(built_lib):
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.Options) == 3 * 8 + 2 * 4 + 8
+    assert C.sizeof(_lib.Options) == 3 * 8 + 2 * 4 + 8 + 8
     assert C.sizeof(_lib.Stats) == 4 * 4 + 14 * 8
 
 

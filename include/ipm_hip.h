@@ -146,7 +146,7 @@ int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl);
  * Only filled when profiling was requested with ipm_set_profiling(h, 1). */
 int ipm_set_profiling(ipm_handle* h, int enable);
 /* Diagnostic builds only (environment IPM_POTRF_STAMPS=1 at ipm_create): s_memtime stamps of the first
- * diagonal-block factorization, 4 waves x 64 slots.  IPM_ERR_STATE otherwise. */
+ * diagonal-block factorization, 8 waves x 64 slots.  IPM_ERR_STATE otherwise. */
 int ipm_debug_get_stamps(ipm_handle* h, long long* out);
 int ipm_get_phase_ms(ipm_handle* h, double out[4]);
 

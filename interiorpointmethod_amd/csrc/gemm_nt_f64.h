@@ -61,7 +61,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SCALE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2)
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2)   // two workgroups per CU
 void gemm_nt_f64_kernel(GemmNT g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;

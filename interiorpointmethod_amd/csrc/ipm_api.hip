@@ -267,7 +267,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
     CREATE_TRY(hipMalloc((void**)&h->d_flags, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     CREATE_TRY(hipMemset(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
-    if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 4 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 4 * 64 * sizeof(long long))); }
+    if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
@@ -519,6 +519,8 @@ static int enqueue_form(ipm_handle* h, const double* d) {
     switch (h->form_variant) {
         case 1: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream))); break;               // no split-K
         case 2: HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(g, h->stream, h->slab, 256))); break;  // BK=32, 1 wg/CU
+        case 3: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(g, h->stream, h->slab, 512))); break;  // 8 waves/wg, 4 waves/SIMD
+        case 4: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(g, h->stream, h->slab, 512))); break;
         default: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;
     }
     return IPM_OK;
@@ -546,9 +548,9 @@ static int enqueue_factor(ipm_handle* h) {
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
-            hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(256), 0, sm, pd);
+            hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         } else {
-            hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(256), 0, sm, pd);
+            hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         }
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
         if (rem <= 0) break;
@@ -736,7 +738,7 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
 // diagnostic: copy the s_memtime stamps of the first diagonal-block factorization (4 waves x 64 slots)
 extern "C" int ipm_debug_get_stamps(ipm_handle* h, long long* out) {
     if (!h || !out || !h->stamp_buf) return fail(h, IPM_ERR_STATE, "stamps not enabled (IPM_POTRF_STAMPS=1)");
-    HIP_TRY(h, hipMemcpy(out, h->stamp_buf, 4 * 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out, h->stamp_buf, 8 * 64 * sizeof(long long), hipMemcpyDeviceToHost));
     return IPM_OK;
 }
 

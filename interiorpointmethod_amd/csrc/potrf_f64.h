@@ -85,70 +85,104 @@ __device__ __forceinline__ double fast_rcp(double p) {
     return __builtin_fma(y, t, y);
 }
 
-// Factor the 16 x 16 tile at (c0,c0) in place; lane i (< 16) owns row i (lanes >= 16 mirror).
-// Wave-level, registers + v_readlane only (an LDS round trip per pivot measured slower).
-// The elimination keeps UNSCALED columns, T[r][j] = L[r][j] L[j][j], so that a pivot step has
-// only 1/p_j on its dependent chain and the v_readlane broadcasts of column j do not wait for it:
-//   T[r][c] -= T[r][j] * (T[c][j] / p_j) ;  the 1/sqrt(p) scaling happens once at the end.
-__device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double thresh, double big, double* dinv_s) {
-    const int i = lane & 15;
-    double t[16];
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + i) * WLD + c0 + c]);
-        t[c] = v.x; t[c + 1] = v.y;
+// value of lane (row-of-16, k) for every lane of the same 16-lane row: v_mov_b32_dpp row_newbcast:k
+// (k must be a compile-time constant after unrolling).
+__device__ __forceinline__ double row_bcast(double v, int k) {
+    union { double d; int i[2]; } u, r;
+    u.d = v; r.d = 0.0;
+    switch (k) {
+#define IPM_RB(K) case K: r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + K, 0xf, 0xf, false); \
+                          r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + K, 0xf, 0xf, false); break;
+        IPM_RB(0) IPM_RB(1) IPM_RB(2) IPM_RB(3) IPM_RB(4) IPM_RB(5) IPM_RB(6) IPM_RB(7)
+        IPM_RB(8) IPM_RB(9) IPM_RB(10) IPM_RB(11) IPM_RB(12) IPM_RB(13) IPM_RB(14) IPM_RB(15)
+#undef IPM_RB
     }
-    double dinv[16];
+    return r.d;
+}
+
+// Factor the 16 x 16 tile at (c0,c0) in place.  Wave-level, all 64 lanes in a 2-D layout:
+// lane (q = lane>>4, c = lane&15) holds T[q+4a][c], a = 0..3, of the FULL symmetric tile.
+// Pivot step j needs, per lane, the column entries T[r][j] of its four rows (one DPP row broadcast
+// each: they sit in lane (q, j)) and the row entry T[j][c] = T[c][j] of its column (one 64-lane
+// shuffle from lane (j&3, c)); only 1/p_j is on the dependent chain because the elimination keeps
+// UNSCALED columns (T[r][j] = L[r][j] L[j][j]):  T[r][c] -= T[r][j] T[j][c] / p_j,  r, c > j.
+// About 25 instructions per pivot instead of ~65 for the one-lane-per-row / v_readlane form.
+__device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double thresh, double big, double* dinv_s) {
+    const int q = lane >> 4, c = lane & 15;
+    double t[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) t[a] = W[(c0 + q + 4 * a) * WLD + c0 + c];
+    double myd = 0.0;                                        // 1/sqrt(p_c) of this lane's column
     int nfix = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double p = readlane_f64(t[j], j);
-        if (!(p > thresh)) { p = big; ++nfix; if (i == j) t[j] = big; }
+        const int ja = j >> 2, jq = j & 3;
+        double p = readlane_f64(t[ja], 16 * jq + j);         // wave-uniform pivot
+        if (!(p > thresh)) { p = big; ++nfix; if (lane == 16 * jq + j) t[ja] = big; }
         const double rp = fast_rcp(p);
-        double root;
-        sqrt_rsqrt(p, root, dinv[j]);                     // off the dependent chain
+        double root, rinv;
+        sqrt_rsqrt(p, root, rinv);
+        myd = (c == j) ? rinv : myd;
+        const double rowc = __shfl(t[ja], 16 * jq + c, 64) * rp;     // T[j][c] / p_j
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-            double lc = readlane_f64(t[j], c) * rp;       // T[c][j] / p_j  (wave-uniform)
-            if (i >= c) t[c] = __builtin_fma(-t[j], lc, t[c]);
+        for (int a = 0; a < 4; ++a) {
+            const double colr = row_bcast(t[a], j);          // T[q+4a][j]
+            if (q + 4 * a > j && c > j) t[a] = __builtin_fma(-colr, rowc, t[a]);
         }
     }
-    if (lane < 16) {
-        dinv_s[c0 + i] = [&] { double d = 0.0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) d = (i == j) ? dinv[j] : d;
-            return d; }();
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c <= i) W[(c0 + i) * WLD + c0 + c] = t[c] * dinv[c];     // L[i][c] = T[i][c] / sqrt(p_c)
+    for (int a = 0; a < 4; ++a) {
+        const int r = q + 4 * a;
+        if (c <= r) W[(c0 + r) * WLD + c0 + c] = t[a] * myd;        // L[r][c] = T[r][c] / sqrt(p_c)
     }
+    if (q == 0) dinv_s[c0 + c] = myd;
     return nfix;
 }
 
-// X = inv(T) for the factored tile at (c0,c0); lane c (< 16) computes column c.  Wave-level.
+// X = inv(T) for the factored tile at (c0,c0).  Same 2-D layout: lane (q, i) holds X[q+4a][i]
+// (column i) and L[q+4a][i]; column sweep k: x_k of every column comes from lane (k&3, i) by a
+// shuffle, L[r][k] from lane (q, k) by a DPP row broadcast.
 __device__ __forceinline__ void invert_tile(double* W, int c0, int lane, const double* dinv_s) {
-    const int i = lane & 15;
-    double t[16];
+    const int q = lane >> 4, i = lane & 15;
+    double x[4], tl[4];
 #pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + i) * WLD + c0 + c]);
-        t[c] = v.x; t[c + 1] = v.y;
+    for (int a = 0; a < 4; ++a) {
+        const int r = q + 4 * a;
+        x[a] = (r == i) ? 1.0 : 0.0;
+        tl[a] = W[(c0 + r) * WLD + c0 + i];
     }
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = (r == i) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        x[k] *= dinv_s[c0 + k];                                  // X[k][i]
+        const int ka = k >> 2, kq = k & 3;
+        const double dk = dinv_s[c0 + k];
+        if (q == kq) x[ka] *= dk;                            // X[k][i], final
+        const double xk = __shfl(x[ka], 16 * kq + i, 64);
 #pragma unroll
-        for (int r = k + 1; r < 16; ++r)                         // eliminate column k from the rows below
-            x[r] = __builtin_fma(-readlane_f64(t[k], r), x[k], x[r]);
+        for (int a = 0; a < 4; ++a) {
+            const double lrk = row_bcast(tl[a], k);          // L[q+4a][k]
+            if (q + 4 * a > k) x[a] = __builtin_fma(-lrk, xk, x[a]);
+        }
     }
-    if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c >= i) W[(c0 + i) * WLD + c0 + c + 1] = x[c];   // X[c][i] -> row c0+i, col c0+c+1
+    for (int a = 0; a < 4; ++a) {
+        const int r = q + 4 * a;
+        if (r >= i) W[(c0 + i) * WLD + c0 + r + 1] = x[a];  // X[r][i] -> row c0+i, col c0+r+1
     }
+}
+
+// Four rows of the panel below tile (c0,c0) per wave: lane (q, c) owns element c of row r0+q and keeps
+// row c of T in registers; column sweep with one DPP row broadcast per step (x_k from lane (q,k)).
+// ~0.7K cycles for 4 rows against ~4.5K for the one-thread-per-row form: used so that the rows the
+// next pivot tile depends on are ready early.  Wave-level.
+__device__ __forceinline__ void substitute_rows4(double* W, int c0, int r0, int lane, const double* trow, double dc) {
+    const int q = lane >> 4, c = lane & 15;
+    double p = W[(r0 + q) * WLD + c0 + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double xk = row_bcast(p * dc, k);              // x_k = p_k / T[k][k]
+        p = (c == k) ? xk : ((c > k) ? __builtin_fma(-xk, trow[k], p) : p);
+    }
+    W[(r0 + q) * WLD + c0 + c] = p;
 }
 
 // one row of the panel below tile (c0,c0): v = p * T^{-T} by forward substitution.  Thread-level.
@@ -226,8 +260,10 @@ __device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, 
 // STAMP = true is a diagnostic instantiation (tools/potrf_stamps.py): every wave records s_memtime
 // at each phase boundary into a.stamps[wave*64 + slot]; the production kernel carries no stamps.
 #define IPM_STAMP(slot) do { if (STAMP && lane == 0) a.stamps[wave * 64 + (slot)] = (long long)clock64(); } while (0)
+constexpr int PD_THREADS = 512;      // 8 waves: wave 0 runs the serial pivot chain, waves 1..7 the MFMA work
+
 template <bool STAMP>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
+__global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     if (a.done && *a.done) return;
     __shared__ __attribute__((aligned(16))) double W[NB * WLD];
     __shared__ double dinv_s[NB];
@@ -238,19 +274,19 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
     const double thresh = a.eps * (*a.maxdiag);
 
     IPM_STAMP(0);
-    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all 32 loads of a
-    //      thread are issued before the first LDS write (one memory latency instead of four)
+    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a
+    //      thread are issued before the first LDS write (one memory latency)
     {
-        f64x2 v[32];
+        f64x2 v[16];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            int idx = tid + u * 256;
+        for (int u = 0; u < 16; ++u) {
+            int idx = tid + u * PD_THREADS;
             int i = idx >> 6, c2 = (idx & 63) * 2;
             v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
         }
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            int idx = tid + u * 256;
+        for (int u = 0; u < 16; ++u) {
+            int idx = tid + u * PD_THREADS;
             int i = idx >> 6, c2 = (idx & 63) * 2;
             if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
@@ -269,15 +305,24 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
     IPM_STAMP(3);
 
     // Phase schedule per 16-wide panel jb (two barriers per panel):
-    //   P2(jb): forward substitution of the panel rows below tile jb (threads 0..16*nrt-1)
+    //   P2(jb): forward substitution of the panel rows below tile jb, four rows per wave pass (DPP form)
     //   P3(jb): wave 0 : update tile (jb+1,jb+1) and factor it (runs ahead on the serial pivot chain)
-    //           wave 3 : invert tile jb, then shares the item list
-    //           waves 1,2: item list = rest of the trailing update of panel jb, then block row jb-1 of
-    //                      inv(L) (its diagonal tile inverse was produced in P3(jb-1))
+    //           wave 7 : invert tile jb, then shares the item list
+    //           waves 1..6: item list = rest of the trailing update of panel jb, then block row jb-1 of
+    //                       inv(L) (its diagonal tile inverse was produced in P3(jb-1))
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16;
         const int nrt = NB / 16 - jb - 1;                 // 16-row tiles below the pivot tile
-        if (tid < 16 * nrt) substitute_row(W, c0, c0 + 16 + tid, dinv_s);
+        if (nrt > 0) {
+            double trow[16];
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + fr) * WLD + c0 + k]);
+                trow[k] = v.x; trow[k + 1] = v.y;
+            }
+            const double dc = dinv_s[c0 + fr];
+            for (int g = wave; g < 4 * nrt; g += 8) substitute_rows4(W, c0, c0 + 16 + 4 * g, lane, trow, dc);
+        }
         IPM_STAMP(4 + jb * 4);
         __syncthreads();
         IPM_STAMP(5 + jb * 4);
@@ -285,12 +330,12 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
             update_tile(W, c0, c0 + 16, c0 + 16, fr, fk);
             nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s);
         } else {
-            if (wave == 3) invert_tile(W, c0, lane, dinv_s);
+            if (wave == 7) invert_tile(W, c0, lane, dinv_s);
             // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1
             const int ntile = nrt * (nrt + 1) / 2;
             const int nupd = ntile > 0 ? ntile - 1 : 0;
             const int ninv = jb >= 1 ? jb - 1 : 0;
-            const int nw = (nrt > 0) ? 3 : 4;             // last panel: wave 0 has no pivot tile left
+            const int nw = (nrt > 0) ? 7 : 8;             // last panel: wave 0 has no pivot tile left
             const int me = (nrt > 0) ? wave - 1 : wave;
             for (int it = me; it < nupd + ninv; it += nw) {
                 if (it < nupd) {
@@ -310,29 +355,28 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(PotrfDiag a) {
         IPM_STAMP(7 + jb * 4);
     }
     // last block row of inv(L): needs the tile inverse of panel 7 (made in P3(7)) and row 6 (also P3(7))
-    for (int jt = wave; jt < NB / 16 - 1; jt += 4) inverse_tile(W, NB / 16 - 1, jt, fr, fk);
+    for (int jt = wave; jt < NB / 16 - 1; jt += 8) inverse_tile(W, NB / 16 - 1, jt, fr, fk);
     IPM_STAMP(38);
     __syncthreads();
     IPM_STAMP(39);
 
-    // ---- write back: L (lower) to B, inverse to `inv` (dense, zero above the diagonal)
+    // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero
+    //      from the handle's initial memset and is never written)
 #pragma unroll 8
-    for (int u = 0; u < 32; ++u) {
-        int idx = tid + u * 256;
+    for (int u = 0; u < 16; ++u) {
+        int idx = tid + u * PD_THREADS;
         int i = idx >> 6, j = (idx & 63) * 2;
         if (j <= i) {
             double l0 = W[i * WLD + j], l1 = W[i * WLD + j + 1];
-            if (j + 1 <= i) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){l0, l1};
-            else a.Bkk[(int64_t)i * a.ld + j] = l0;
+            double x0 = W[j * WLD + i + 1];
+            if (j + 1 <= i) {
+                *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){l0, l1};
+                *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){x0, W[(j + 1) * WLD + i + 1]};
+            } else {
+                a.Bkk[(int64_t)i * a.ld + j] = l0;
+                a.inv[i * NB + j] = x0;
+            }
         }
-    }
-#pragma unroll 8
-    for (int u = 0; u < 32; ++u) {
-        int idx = tid + u * 256;
-        int i = idx >> 6, j = (idx & 63) * 2;
-        double x0 = (j <= i) ? W[j * WLD + i + 1] : 0.0;
-        double x1 = (j + 1 <= i) ? W[(j + 1) * WLD + i + 1] : 0.0;
-        *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){x0, x1};
     }
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);

@@ -11,10 +11,10 @@ M = rng.standard_normal((m, m + 10)); B = M @ M.T + 0.1 * np.eye(m); rhs = rng.s
 with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
     for _ in range(3):
         z, nfix = sv.solve_linear(B, rhs)
-    buf = (C.c_longlong * 256)()
+    buf = (C.c_longlong * 512)()
     sv._lib.ipm_debug_get_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     assert sv._lib.ipm_debug_get_stamps(sv._h, buf) == 0
-st = np.array(buf[:], dtype=np.int64).reshape(4, 64)
+st = np.array(buf[:], dtype=np.int64).reshape(8, 64)
 t0 = st[:, 0].min()
 print("resid", np.linalg.norm(B @ z.ravel() - rhs) / np.linalg.norm(rhs))
 print("cycles since kernel start, per wave: load_done, factor0_done(w0), after_sync")

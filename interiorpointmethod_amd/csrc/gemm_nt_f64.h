@@ -47,6 +47,10 @@ struct GemmNT {
     double* slab;
     int tile_offset;            // logical tile = tile_offset + index (used to skip the first lower tile)
     const int* tile_order;      // optional: logical tile -> (ti << 16 | tj), a 2-D patch order for L2 reuse
+    int64_t sP, sQ, sC;         // batch strides (elements) applied with blockIdx.y; 0 for a single problem
+    int batch;                  // gridDim.y (>= 1; no split-K when > 1)
+    int64_t sP2, sQ2, sC2;      // second-level batch strides applied with blockIdx.z
+    int batch2;                 // gridDim.z (>= 1)
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -114,8 +118,8 @@ void gemm_nt_f64_kernel(GemmNT g) {
         }
     }
     const int row0 = ti * BM, col0 = tj * BN;
-    const double* Pg = g.P + (int64_t)row0 * g.ldp;
-    const double* Qg = g.Q + (int64_t)col0 * g.ldq;
+    const double* Pg = g.P + (int64_t)blockIdx.y * g.sP + (int64_t)blockIdx.z * g.sP2 + (int64_t)row0 * g.ldp;
+    const double* Qg = g.Q + (int64_t)blockIdx.y * g.sQ + (int64_t)blockIdx.z * g.sQ2 + (int64_t)col0 * g.ldq;
 
     f64x4 acc[MI][NI];
 #pragma unroll
@@ -193,7 +197,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
                 for (int q = 0; q < 4; ++q) sb[(i * 16 + 4 * q) * BN + j * 16] = acc[i][j][q];
         return;
     }
-    double* cbase = g.C + (int64_t)(row0 + wm * WTM + fk) * g.ldc + col0 + wn * WTN + fr;
+    double* cbase = g.C + (int64_t)blockIdx.y * g.sC + (int64_t)blockIdx.z * g.sC2 + (int64_t)(row0 + wm * WTM + fk) * g.ldc + col0 + wn * WTN + fr;
     if (g.beta != 0.0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -277,6 +281,9 @@ inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nu
     int tiles = (g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn) - skip_first;
     g.tile_offset = skip_first;
     if (tiles <= 0) return hipSuccess;
+    if (g.batch < 1) { g.batch = 1; g.sP = g.sQ = g.sC = 0; }
+    if (g.batch2 < 1) { g.batch2 = 1; g.sP2 = g.sQ2 = g.sC2 = 0; }
+    if (g.batch > 1 || g.batch2 > 1) slab = nullptr;
     const int nk = g.K / BK;
     g.n_direct = tiles; g.split_p = 1; g.chunk_stages = nk; g.slab = nullptr;
     int grid = tiles;
@@ -295,10 +302,10 @@ inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nu
         }
     }
     if (g.w)
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), dim3(grid),
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), dim3(grid, g.batch, g.batch2),
                            dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
     else
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), dim3(grid),
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), dim3(grid, g.batch, g.batch2),
                            dim3(64 * WAVES_M * WAVES_N), 0, stream, g);
     if (g.slab)
         hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(BM * BN / 1024, tiles - g.n_direct), dim3(256), 0,

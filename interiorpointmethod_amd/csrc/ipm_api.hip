@@ -19,6 +19,7 @@
 #include "gemm_nt_f64.h"
 #include "potrf_f64.h"
 #include "sparse_ops.h"
+#include "trsv_grouped.h"
 #include "vector_ops.h"
 
 #include <algorithm>
@@ -36,6 +37,11 @@ struct ipm_handle {
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
+    bool groups_done_in_factor = false;   // group inverses were enqueued on the third stream inside enqueue_factor
+    hipStream_t stream3 = nullptr;
+    std::vector<hipEvent_t> ev_grp;
+    int grouped_trsv = 1;                 // 1024-row group inverses + GEMV solves when nblk % 8 == 0, nblk >= 16
+    double *gXT = nullptr, *gX = nullptr, *gS = nullptr, *gPart = nullptr;   // own allocation
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
@@ -265,6 +271,21 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreate(&h->ev1));
     if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
     if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
+    if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
+    if (h->grouped_trsv && h->nblk % GS == 0 && h->nblk >= 2 * GS) {
+        const size_t nG = (size_t)h->nblk / GS;
+        CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        h->ev_grp.assign(nG, nullptr);
+        for (size_t g = 0; g < nG; ++g) CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp[g], hipEventDisableTiming));
+        CREATE_TRY(hipMalloc((void**)&h->gXT, sizeof(double) * nG * GR * GR));
+        CREATE_TRY(hipMalloc((void**)&h->gX, sizeof(double) * nG * GR * GR));
+        CREATE_TRY(hipMalloc((void**)&h->gS, sizeof(double) * nG * 512 * 512));
+        CREATE_TRY(hipMalloc((void**)&h->gPart, sizeof(double) * 16 * (size_t)h->mp));
+        CREATE_TRY(hipMemset(h->gXT, 0, sizeof(double) * nG * GR * GR));     // blocks below the block diagonal stay zero
+        CREATE_TRY(hipMemset(h->gX, 0, sizeof(double) * nG * GR * GR));      // blocks above the block diagonal stay zero
+    } else {
+        h->grouped_trsv = 0;
+    }
     CREATE_TRY(hipMalloc((void**)&h->d_flags, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     CREATE_TRY(hipMemset(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
@@ -289,7 +310,8 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-    for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk})
+    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
+    for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk, &h->ev_grp})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -298,6 +320,10 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->h_sc) (void)hipHostFree(h->h_sc);
     if (h->stamp_buf) (void)hipFree(h->stamp_buf);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->gXT) (void)hipFree(h->gXT);
+    if (h->gX) (void)hipFree(h->gX);
+    if (h->gS) (void)hipFree(h->gS);
+    if (h->gPart) (void)hipFree(h->gPart);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -512,6 +538,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
         return IPM_OK;
     }
     GemmNT g;
+    g.batch = 1; g.sP = g.sQ = g.sC = 0; g.batch2 = 1; g.sP2 = g.sQ2 = g.sC2 = 0;
     g.tile_order = h->d_tile_order;
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;
@@ -532,6 +559,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
 static int enqueue_factor(ipm_handle* h) {
     const int* done = &h->sc->done;
+    h->groups_done_in_factor = false;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     const bool la = h->lookahead != 0 && h->nblk > 2;
@@ -556,12 +584,12 @@ static int enqueue_factor(ipm_handle* h) {
         if (rem <= 0) break;
         double* panel = h->B + (int64_t)(k + 1) * NB * h->mp + (int64_t)k * NB;
         GemmNT t;                                                   // L_ik = B_ik inv(L_kk)^T, in place
-        t.tile_order = nullptr;
+        t.tile_order = nullptr; t.batch = 1; t.sP = t.sQ = t.sC = 0; t.batch2 = 1; t.sP2 = t.sQ2 = t.sC2 = 0;
         t.P = panel; t.ldp = h->mp; t.Q = pd.inv; t.ldq = NB; t.w = nullptr;
         t.C = panel; t.ldc = h->mp; t.M = rem; t.N = NB; t.K = NB;
         t.alpha = 1.0; t.beta = 0.0; t.lower = 0; t.unit_diag_from = -1; t.done = done;
         GemmNT u;                                                   // B_ij -= L_ik L_jk^T
-        u.tile_order = nullptr;
+        u.tile_order = nullptr; u.batch = 1; u.sP = u.sQ = u.sC = 0; u.batch2 = 1; u.sP2 = u.sQ2 = u.sC2 = 0;
         u.P = panel; u.ldp = h->mp; u.Q = panel; u.ldq = h->mp; u.w = nullptr;
         u.C = h->B + (int64_t)(k + 1) * NB * (h->mp + 1); u.ldc = h->mp; u.M = rem; u.N = rem; u.K = NB;
         u.alpha = -1.0; u.beta = 1.0; u.lower = 1; u.unit_diag_from = -1; u.done = done;
@@ -591,8 +619,79 @@ static int enqueue_factor(ipm_handle* h) {
     return IPM_OK;
 }
 
+// X_g, XT_g = inv of every 1024 x 1024 diagonal group of the factor and its transpose (trsv_grouped.h):
+// recursive doubling 128 -> 256 -> 512 -> 1024, three GEMMs per level batched over (pairs in a group,
+// groups).  After enqueue_factor, on the main stream.
+static int enqueue_group_inverses(ipm_handle* h) {
+    if (!h->grouped_trsv) return IPM_OK;
+    const int nG = h->nblk / GS;
+    const int* done = &h->sc->done;
+    hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, h->nblk), dim3(32, 8), 0, h->stream, h->invD, h->gXT, h->gX, 0, done);
+    for (int hs = 128; hs < GR; hs *= 2) {
+        const int np = GR / (2 * hs);                     // pairs per group
+        GemmNT t;
+        t.tile_order = nullptr; t.w = nullptr; t.done = done; t.lower = 0; t.unit_diag_from = -1;
+        t.M = hs; t.N = hs; t.K = hs; t.beta = 0.0; t.batch = np; t.batch2 = nG;
+        const int64_t pX = (int64_t)2 * hs * (GR + 1), gXs = (int64_t)GR * GR;        // pair / group strides in X, XT
+        const int64_t pL = (int64_t)2 * hs * (h->mp + 1), gL = (int64_t)GR * (h->mp + 1);
+        const int64_t pS = (int64_t)hs * hs, gSs = (int64_t)512 * 512;
+        GemmNT a = t;                                     // S = XT11 * L21^T
+        a.P = h->gXT; a.ldp = GR; a.sP = pX; a.sP2 = gXs;
+        a.Q = h->B + (int64_t)hs * h->mp; a.ldq = h->mp; a.sQ = pL; a.sQ2 = gL;
+        a.C = h->gS; a.ldc = hs; a.sC = pS; a.sC2 = gSs; a.alpha = 1.0;
+        HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(a, h->stream)));
+        GemmNT b = t;                                     // X21 = -X22 * S^T
+        b.P = h->gX + (int64_t)hs * GR + hs; b.ldp = GR; b.sP = pX; b.sP2 = gXs;
+        b.Q = h->gS; b.ldq = hs; b.sQ = pS; b.sQ2 = gSs;
+        b.C = h->gX + (int64_t)hs * GR; b.ldc = GR; b.sC = pX; b.sC2 = gXs; b.alpha = -1.0;
+        HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(b, h->stream)));
+        GemmNT c = t;                                     // XT12 = -S * X22^T
+        c.P = h->gS; c.ldp = hs; c.sP = pS; c.sP2 = gSs;
+        c.Q = h->gX + (int64_t)hs * GR + hs; c.ldq = GR; c.sQ = pX; c.sQ2 = gXs;
+        c.C = h->gXT + hs; c.ldc = GR; c.sC = pX; c.sC2 = gXs; c.alpha = -1.0;
+        HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(c, h->stream)));
+    }
+    HIP_TRY(h, hipGetLastError());
+    return IPM_OK;
+}
+
+static void launch_dense_gemv_n(ipm_handle* h, const double* A, int64_t lda, int rows, int cols, const double* v, double sa,
+                                double sb, const double* add, double* out) {
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream, A, lda, rows, cols, v, sa, sb,
+                       add, out, &h->sc->done);
+}
+
+// out = B^{-1} r with the 1024-row group inverses: 4 group steps per sweep at m = 4096
+static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out) {
+    const int nG = h->nblk / GS;
+    const int* done = &h->sc->done;
+    double* z = h->t2;
+    for (int g = 0; g < nG; ++g) {                                        // forward: L z = r
+        launch_dense_gemv_n(h, h->gX + (int64_t)g * GR * GR, GR, GR, GR, r + (int64_t)g * GR, 1.0, 0.0, nullptr, z + (int64_t)g * GR);
+        int below = (int)(h->mp - (int64_t)(g + 1) * GR);
+        if (below > 0) {
+            double* rb = r + (int64_t)(g + 1) * GR;
+            launch_dense_gemv_n(h, h->B + (int64_t)(g + 1) * GR * h->mp + (int64_t)g * GR, h->mp, below, GR, z + (int64_t)g * GR, -1.0, 1.0,
+                                rb, rb);
+        }
+    }
+    for (int g = nG - 1; g >= 0; --g) {                                   // backward: L^T w = z
+        launch_dense_gemv_n(h, h->gXT + (int64_t)g * GR * GR, GR, GR, GR, z + (int64_t)g * GR, 1.0, 0.0, nullptr, out + (int64_t)g * GR);
+        int left = g * GR;
+        if (left > 0) {
+            dim3 grid((unsigned)((left + 511) / 512), 16);
+            hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->B + (int64_t)g * GR * h->mp, h->mp, GR / 16, left,
+                               out + (int64_t)g * GR, h->gPart, done);
+            hipLaunchKernelGGL(sub_partials_kernel, dim3((unsigned)((left + 255) / 256)), dim3(256), 0, h->stream, z, h->gPart, left, 16, done);
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return IPM_OK;
+}
+
 // out = B^{-1} r  (r is consumed; uses t2 as the intermediate)
 static int enqueue_potrs(ipm_handle* h, double* r, double* out) {
+    if (h->grouped_trsv) return enqueue_potrs_grouped(h, r, out);
     if (h->persistent_trsv && h->nblk >= 2 && h->nblk <= 240) {
         // flags: [0,nblk) forward, [nblk,2nblk) backward, then the timeout word; zeroed per call
         HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk), h->stream));
@@ -669,6 +768,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     if ((rc = enqueue_form(h, h->d))) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
     if ((rc = enqueue_factor(h))) return rc;
+    if ((rc = enqueue_group_inverses(h))) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
     if ((rc = enqueue_predictor(h, ev ? ev + 4 : nullptr))) return rc;
     if ((rc = enqueue_corrector(h, ev ? ev + 6 : nullptr))) return rc;
@@ -713,6 +813,7 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
         if ((rc = enqueue_residuals(h))) return rc;
         if ((rc = enqueue_form(h, h->d))) return rc;
         if ((rc = enqueue_factor(h))) return rc;
+        if ((rc = enqueue_group_inverses(h))) return rc;
         if ((rc = enqueue_predictor(h, nullptr))) return rc;
         VecArgs a = vec_args(h);
         hipLaunchKernelGGL(mu_aff_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);   // alpha_aff for stats
@@ -862,6 +963,7 @@ extern "C" int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, con
     HIP_TRY(h, hipMemcpyAsync(h->t1, rhs, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
     int rc = enqueue_factor(h);
     if (rc) return rc;
+    if ((rc = enqueue_group_inverses(h))) return rc;
     if ((rc = enqueue_potrs(h, h->t1, h->dy))) return rc;
     HIP_TRY(h, hipMemcpyAsync(z, h->dy, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
     if ((rc = read_scalars(h))) return rc;

@@ -1,0 +1,68 @@
+// trsv_grouped.h -- triangular solves with 1024-row groups (gfx950).
+//
+// The per-128-block substitution (potrf_f64.h: trsv_*_step_kernel) is launch-latency bound:
+// 2 x 32 dependent launches per solve at m = 4096, ~8 us each, four sweeps per iteration.  Here
+// the factor's diagonal is regrouped into 1024 x 1024 lower-triangular blocks D_g whose explicit
+// inverses X_g = inv(D_g) are assembled right after the factorization from the 128-block inverses
+// the Cholesky already produced (batched MFMA GEMMs over all groups):
+// by recursive doubling (128 -> 256 -> 512 -> 1024), three batched NT GEMMs per level that keep both
+// X and XT = X^T current (the K-contiguous "NT" kernel needs one operand of each kind):
+//     S   = XT11 * L21^T ;   X21 = -X22 * S^T ;   XT12 = -S * X22^T        ( = inv([[L11,0],[L21,L22]]) )
+// A solve is then 4 group steps of dense GEMVs at HBM speed instead of 32 block steps:
+//     forward : z_g = X_g r_g ;  r_below -= L[below, g] z_g
+//     backward: w_g = XT_g z_g ;  z_left  -= L[g, left]^T w_g
+// Same arithmetic as the block substitution up to rounding (explicit inverses of well-scaled
+// 1024-blocks; the 128-block inverses they are built from are used by the Cholesky anyway).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gemm_nt_f64.h"
+
+namespace ipm {
+
+constexpr int GS = 8;                 // 128-blocks per group
+constexpr int GR = GS * 128;          // rows per group
+
+// X_g[a*128 + r][a*128 + c] = inv(L_bb)[r][c] and XT_g = its transpose, for every 128-block b = 8g + a.
+// grid (4, 4, nblocks), block (32, 8).
+__global__ void group_diag_transpose_kernel(const double* __restrict__ invD, double* XT, double* X, int b0, const int* done) {
+    if (done && *done) return;
+    __shared__ double tile[32][33];
+    const int b = b0 + blockIdx.z, g = b / GS, a = b % GS;
+    const double* src = invD + (int64_t)b * 128 * 128;
+    double* dst = XT + (int64_t)g * GR * GR + (int64_t)(a * 128) * GR + a * 128;
+    double* dsx = X + (int64_t)g * GR * GR + (int64_t)(a * 128) * GR + a * 128;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        double v = src[(int64_t)(by + j) * 128 + bx + threadIdx.x];
+        tile[j][threadIdx.x] = v;
+        dsx[(int64_t)(by + j) * GR + bx + threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) dst[(int64_t)(bx + j) * GR + by + threadIdx.x] = tile[threadIdx.x][j];
+}
+
+// X_g = XT_g^T for every group.  grid (32, 32, nG), block (32, 8).
+__global__ void group_transpose_kernel(const double* __restrict__ XT, double* X, int g0, const int* done) {
+    if (done && *done) return;
+    __shared__ double tile[32][33];
+    const double* src = XT + (int64_t)(g0 + blockIdx.z) * GR * GR;
+    double* dst = X + (int64_t)(g0 + blockIdx.z) * GR * GR;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) tile[j][threadIdx.x] = src[(int64_t)(by + j) * GR + bx + threadIdx.x];
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) dst[(int64_t)(bx + j) * GR + by + threadIdx.x] = tile[threadIdx.x][j];
+}
+
+// z[c] -= sum_rc part[rc*np + c], c < np  (fixed order)
+__global__ __launch_bounds__(256) void sub_partials_kernel(double* z, const double* __restrict__ part, int np, int rc,
+                                                           const int* done) {
+    if (done && *done) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= np) return;
+    double s = 0.0;
+    for (int r = 0; r < rc; ++r) s += part[(int64_t)r * np + c];
+    z[c] -= s;
+}
+
+}  // namespace ipm

@@ -56,7 +56,7 @@ def test_form_wide_dynamic_range():
     assert rel(B, ref) < 1e-12
 
 
-@pytest.mark.parametrize("m", [1, 16, 100, 128, 129, 300, 700, 1500])
+@pytest.mark.parametrize("m", [1, 16, 100, 128, 129, 300, 700, 1500, 2048, 3000])   # >= 2048: grouped-inverse solves
 def test_cholesky_and_solve(m):
     rng = np.random.default_rng(m)
     M = rng.standard_normal((m, m + 10))

@@ -111,7 +111,8 @@ static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     L.np = round_up(n, 64);
     L.nblk = (int)(L.mp / NB);
     int64_t c64 = L.mp / 64;
-    L.rc_chunks = (int)(c64 <= 64 ? c64 : 64);
+    L.rc_chunks = (int)(c64 <= 32 ? c64 : 32);          // <= 32 row chunks of A^T u partials (mp/64 must divide evenly)
+    while (L.mp % L.rc_chunks) --L.rc_chunks;
     L.rows_per_chunk = (int)(L.mp / L.rc_chunks);
     while ((int64_t)L.rc_chunks * L.rows_per_chunk < L.mp) ++L.rows_per_chunk;   // (exact by construction)
     int64_t mx = m > n ? m : n;

@@ -330,13 +330,15 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
             update_tile(W, c0, c0 + 16, c0 + 16, fr, fk);
             nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s);
         } else {
-            if (wave == 7) invert_tile(W, c0, lane, dinv_s);
-            // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1
+            // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1.
+            // Wave 7 only inverts tile jb (about as long as wave 0's factorization) while a pivot tile is
+            // left; the item list is shared by waves 1..6 (all 8 waves on the last panel).
             const int ntile = nrt * (nrt + 1) / 2;
             const int nupd = ntile > 0 ? ntile - 1 : 0;
             const int ninv = jb >= 1 ? jb - 1 : 0;
-            const int nw = (nrt > 0) ? 7 : 8;             // last panel: wave 0 has no pivot tile left
-            const int me = (nrt > 0) ? wave - 1 : wave;
+            const int nw = (nrt > 0) ? 6 : 8;
+            int me = (nrt > 0) ? wave - 1 : wave;
+            if (wave == 7) { invert_tile(W, c0, lane, dinv_s); if (nrt > 0) me = nupd + ninv; }
             for (int it = me; it < nupd + ninv; it += nw) {
                 if (it < nupd) {
                     int tix = it + 1;

@@ -549,6 +549,8 @@ static int enqueue_form(ipm_handle* h, const double* d) {
         case 2: HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(g, h->stream, h->slab, 256))); break;  // BK=32, 1 wg/CU
         case 3: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(g, h->stream, h->slab, 512))); break;  // 8 waves/wg, 4 waves/SIMD
         case 4: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(g, h->stream, h->slab, 512))); break;
+        case 5: g.w = nullptr; HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;  // timing probe: no d scaling (WRONG result)
+        case 6: g.tile_order = nullptr; HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;  // timing probe: row-major tile order
         default: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;
     }
     return IPM_OK;

@@ -51,6 +51,13 @@ struct GemmNT {
     int batch;                  // gridDim.y (>= 1; no split-K when > 1)
     int64_t sP2, sQ2, sC2;      // second-level batch strides applied with blockIdx.z
     int batch2;                 // gridDim.z (>= 1)
+    // Cross-stream hand-off without stream events (an event wait costs the pivot chain ~8 us of command-
+    // processor time per Cholesky step): a producer launch on another stream bumps *signal once per
+    // workgroup after an agent-scope release; a SMALL consumer launch polls *wait_on >= wait_count from one
+    // lane (bounded), then acquires.  Only launches of a few workgroups may wait (no CU starvation).
+    unsigned* signal;           // may be null
+    const unsigned* wait_on;    // may be null
+    unsigned wait_count;
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -79,6 +86,18 @@ void gemm_nt_f64_kernel(GemmNT g) {
     static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BK % 4 == 0, "mfma tiling");
 
     if (g.done && *g.done) return;
+    if (g.wait_on) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 24)) break;        // give up (results then fail the parity checks, no hang)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
 
     __shared__ __attribute__((aligned(16))) double lds[2 * (BM + BN) * LDT];
     double* Ps = lds;                           // [2][BM][LDT]
@@ -233,6 +252,15 @@ void gemm_nt_f64_kernel(GemmNT g) {
                 if (g.unit_diag_from >= 0 && r == c && r >= g.unit_diag_from) v = 1.0;
                 cbase[(int64_t)(i * 16 + 4 * q) * g.ldc + j * 16] = v;
             }
+    if (g.signal) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // C tile = beta*C + alpha * (sum of the split_p slabs of that tile, in chunk order); one tail tile per
@@ -285,6 +313,7 @@ inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nu
     int tiles = (g.lower ? ntm * (ntm + 1) / 2 : ntm * ntn) - skip_first;
     g.tile_offset = skip_first;
     if (tiles <= 0) return hipSuccess;
+    if (g.signal || g.wait_on) slab = nullptr;               // hand-off launches are never split
     if (g.batch < 1) { g.batch = 1; g.sP = g.sQ = g.sC = 0; }
     if (g.batch2 < 1) { g.batch2 = 1; g.sP2 = g.sQ2 = g.sC2 = 0; }
     if (g.batch > 1 || g.batch2 > 1) slab = nullptr;

@@ -44,6 +44,8 @@ struct ipm_handle {
     double *gXT = nullptr, *gX = nullptr, *gS = nullptr, *gPart = nullptr;   // own allocation
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
+    unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
+    int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
     int64_t m = 0, n = 0, mp = 0, np = 0;
     int nblk = 0, rc_chunks = 0, rows_per_chunk = 0, vblk = 0;
@@ -94,6 +96,13 @@ static int fail(ipm_handle* h, int code, const char* fmt, ...) {
     } while (0)
 
 static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+static GemmNT gemm_defaults() {
+    GemmNT g;
+    memset(&g, 0, sizeof g);
+    g.alpha = 1.0; g.unit_diag_from = -1; g.batch = 1; g.batch2 = 1;
+    return g;
+}
 
 // ------------------------------------------------------------------------------- layout
 struct Layout {
@@ -289,6 +298,9 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     }
     CREATE_TRY(hipMalloc((void**)&h->d_flags, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     CREATE_TRY(hipMemset(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
+    CREATE_TRY(hipMalloc((void**)&h->d_bulk_done, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));   // [0,nblk) bulk, [nblk,2nblk) crit
+    CREATE_TRY(hipMemset(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
+    if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -321,6 +333,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->h_sc) (void)hipHostFree(h->h_sc);
     if (h->stamp_buf) (void)hipFree(h->stamp_buf);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->d_bulk_done) (void)hipFree(h->d_bulk_done);
     if (h->gXT) (void)hipFree(h->gXT);
     if (h->gX) (void)hipFree(h->gX);
     if (h->gS) (void)hipFree(h->gS);
@@ -538,7 +551,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }
-    GemmNT g;
+    GemmNT g = gemm_defaults();
     g.batch = 1; g.sP = g.sQ = g.sC = 0; g.batch2 = 1; g.sP2 = g.sQ2 = g.sC2 = 0;
     g.tile_order = h->d_tile_order;
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
@@ -567,7 +580,10 @@ static int enqueue_factor(ipm_handle* h) {
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     const bool la = h->lookahead != 0 && h->nblk > 2;
     hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
+    const bool fs = la && h->flag_sync != 0;
+    std::vector<unsigned> bulk_wgs(h->nblk, 0u);          // workgroups of the bulk update of each step
     if (la) {
+        if (fs) HIP_TRY(h, hipMemsetAsync(h->d_bulk_done, 0, sizeof(unsigned) * 2 * (size_t)h->nblk, sm));
         HIP_TRY(h, hipEventRecord(h->ev_fork, sm));
         HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_fork, 0));
     }
@@ -586,12 +602,12 @@ static int enqueue_factor(ipm_handle* h) {
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
         if (rem <= 0) break;
         double* panel = h->B + (int64_t)(k + 1) * NB * h->mp + (int64_t)k * NB;
-        GemmNT t;                                                   // L_ik = B_ik inv(L_kk)^T, in place
+        GemmNT t = gemm_defaults();                                 // L_ik = B_ik inv(L_kk)^T, in place
         t.tile_order = nullptr; t.batch = 1; t.sP = t.sQ = t.sC = 0; t.batch2 = 1; t.sP2 = t.sQ2 = t.sC2 = 0;
         t.P = panel; t.ldp = h->mp; t.Q = pd.inv; t.ldq = NB; t.w = nullptr;
         t.C = panel; t.ldc = h->mp; t.M = rem; t.N = NB; t.K = NB;
         t.alpha = 1.0; t.beta = 0.0; t.lower = 0; t.unit_diag_from = -1; t.done = done;
-        GemmNT u;                                                   // B_ij -= L_ik L_jk^T
+        GemmNT u = gemm_defaults();                                 // B_ij -= L_ik L_jk^T
         u.tile_order = nullptr; u.batch = 1; u.sP = u.sQ = u.sC = 0; u.batch2 = 1; u.sP2 = u.sQ2 = u.sC2 = 0;
         u.P = panel; u.ldp = h->mp; u.Q = panel; u.ldq = h->mp; u.w = nullptr;
         u.C = h->B + (int64_t)(k + 1) * NB * (h->mp + 1); u.ldc = h->mp; u.M = rem; u.N = rem; u.K = NB;
@@ -601,19 +617,34 @@ static int enqueue_factor(ipm_handle* h) {
             HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sm)));
             continue;
         }
-        HIP_TRY(h, hipEventRecord(h->ev_diag[k], sm));
-        if (k >= 1) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[k - 1], 0));
+        // one event per step on the main stream (after the critical panel rows): every extra record / wait
+        // costs the pivot chain ~6-12 us of command-processor time (profiles/, trace of a step)
         GemmNT tc = t; tc.M = NB;                                   // critical panel rows: block row k+1
+        if (k >= 1) {
+            if (fs && bulk_wgs[k - 1] > 0) { tc.wait_on = h->d_bulk_done + (k - 1); tc.wait_count = bulk_wgs[k - 1]; }
+            else if (!fs) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[k - 1], 0));
+        }
+        // bulk side: the (small) panel launch of the bulk stream polls the completion counter of the critical
+        // panel launch instead of a stream event, unless it is large enough to crowd the CUs while it spins
+        const int tb_wgs = (rem - NB) / 64;
+        const bool crit_flag = fs && rem > NB && tb_wgs <= 256;
+        if (crit_flag) tc.signal = h->d_bulk_done + h->nblk + k;
         HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
-        HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
+        if (!crit_flag) HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
         GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1), as 64x64 sub-tiles
         HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(uc, sm)));
-        HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_diag[k], 0));
+        if (!crit_flag) HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
         if (rem > NB) {
             GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
+            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; }
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
-            HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
-            HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sb, nullptr, 512, /*skip_first=*/1)));
+            GemmNT ub = u;
+            if (fs) {
+                int nt = rem / NB;
+                bulk_wgs[k] = (unsigned)(nt * (nt + 1) / 2 - 1);
+                ub.signal = h->d_bulk_done + k;
+            }
+            HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
         }
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }
@@ -632,7 +663,7 @@ static int enqueue_group_inverses(ipm_handle* h) {
     hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, h->nblk), dim3(32, 8), 0, h->stream, h->invD, h->gXT, h->gX, 0, done);
     for (int hs = 128; hs < GR; hs *= 2) {
         const int np = GR / (2 * hs);                     // pairs per group
-        GemmNT t;
+        GemmNT t = gemm_defaults();
         t.tile_order = nullptr; t.w = nullptr; t.done = done; t.lower = 0; t.unit_diag_from = -1;
         t.M = hs; t.N = hs; t.K = hs; t.beta = 0.0; t.batch = np; t.batch2 = nG;
         const int64_t pX = (int64_t)2 * hs * (GR + 1), gXs = (int64_t)GR * GR;        // pair / group strides in X, XT

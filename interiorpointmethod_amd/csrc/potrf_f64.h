@@ -114,21 +114,37 @@ __device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double t
     for (int a = 0; a < 4; ++a) t[a] = W[(c0 + q + 4 * a) * WLD + c0 + c];
     double myd = 0.0;                                        // 1/sqrt(p_c) of this lane's column
     int nfix = 0;
+    // The 64-lane shuffle that fetches row j (T[j][c]) is taken off the pivot chain: row j+1 is shuffled
+    // BEFORE pivot j's update touches it and then corrected with one FMA (its own update by pivot j is
+    // T[j+1][c] -= T[j+1][j] * T[j][c]/p_j with a wave-uniform T[j+1][j]).
+    double rowcur = __shfl(t[0], c, 64);                     // row 0: T[0][c]
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int ja = j >> 2, jq = j & 3;
         double p = readlane_f64(t[ja], 16 * jq + j);         // wave-uniform pivot
         if (!(p > thresh)) { p = big; ++nfix; if (lane == 16 * jq + j) t[ja] = big; }
+        double rownext = 0.0, mnext = 0.0;
+        if (j + 1 < 16) {
+            const int na = (j + 1) >> 2, nq = (j + 1) & 3;
+            rownext = __shfl(t[na], 16 * nq + c, 64);        // T[j+1][c] before pivot j's update
+            mnext = readlane_f64(t[na], 16 * nq + j);        // T[j+1][j]  (column j is final)
+        }
         const double rp = fast_rcp(p);
-        double root, rinv;
-        sqrt_rsqrt(p, root, rinv);
-        myd = (c == j) ? rinv : myd;
-        const double rowc = __shfl(t[ja], 16 * jq + c, 64) * rp;     // T[j][c] / p_j
+        myd = (c == j) ? p : myd;                            // remember this column's pivot; 1/sqrt after the loop
+        const double rowc = rowcur * rp;                     // T[j][c] / p_j
+        const double rowm = (c > j) ? rowc : 0.0;            // columns <= j are final: masked once per pivot
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const double colr = row_bcast(t[a], j);          // T[q+4a][j]
-            if (q + 4 * a > j && c > j) t[a] = __builtin_fma(-colr, rowc, t[a]);
+            if (a < ja) continue;                            // rows q+4a <= j for every lane: nothing to do (static)
+            double colr = row_bcast(t[a], j);                // T[q+4a][j]
+            if (a == ja) colr = (q > jq) ? colr : 0.0;       // the only row group that straddles the pivot
+            t[a] = __builtin_fma(-colr, rowm, t[a]);
         }
+        rowcur = __builtin_fma(-mnext, rowc, rownext);       // row j+1 after pivot j (valid for c > j)
+    }
+    {   // all 16 reciprocal square roots at once (lane c holds p_c): one vector chain instead of 16 scalar ones
+        double root;
+        sqrt_rsqrt(myd, root, myd);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -151,17 +167,28 @@ __device__ __forceinline__ void invert_tile(double* W, int c0, int lane, const d
         x[a] = (r == i) ? 1.0 : 0.0;
         tl[a] = W[(c0 + r) * WLD + c0 + i];
     }
+    // same trick as factor_tile: row k+1 of X is shuffled before step k updates it and corrected with one
+    // FMA (X[k+1][i] -= L[k+1][k] x_k, L[k+1][k] wave-uniform), so no shuffle sits on the dependent chain
+    double xcur = __shfl(x[0], i, 64);                       // X_pre[0][i]
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int ka = k >> 2, kq = k & 3;
-        const double dk = dinv_s[c0 + k];
-        if (q == kq) x[ka] *= dk;                            // X[k][i], final
-        const double xk = __shfl(x[ka], 16 * kq + i, 64);
+        const double xk = xcur * dinv_s[c0 + k];             // X[k][i], final
+        if (q == kq) x[ka] = xk;
+        double xnext = 0.0, lnext = 0.0;
+        if (k + 1 < 16) {
+            const int na = (k + 1) >> 2, nq = (k + 1) & 3;
+            xnext = __shfl(x[na], 16 * nq + i, 64);          // X_pre[k+1][i] before step k's update
+            lnext = readlane_f64(tl[na], 16 * nq + k);       // L[k+1][k]
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const double lrk = row_bcast(tl[a], k);          // L[q+4a][k]
-            if (q + 4 * a > k) x[a] = __builtin_fma(-lrk, xk, x[a]);
+            if (a < ka) continue;                            // rows <= k for every lane (static)
+            double lrk = row_bcast(tl[a], k);                // L[q+4a][k]
+            if (a == ka) lrk = (q > kq) ? lrk : 0.0;
+            x[a] = __builtin_fma(-lrk, xk, x[a]);
         }
+        xcur = __builtin_fma(-lnext, xk, xnext);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {

@@ -45,6 +45,7 @@ struct ipm_handle {
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
     unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
+    int crit_variant = 1;                 // smaller tiles / deeper K steps for the two critical-path GEMMs
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
     int64_t m = 0, n = 0, mp = 0, np = 0;
@@ -301,6 +302,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipMalloc((void**)&h->d_bulk_done, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));   // [0,nblk) bulk, [nblk,2nblk) crit
     CREATE_TRY(hipMemset(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
+    if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -629,14 +631,16 @@ static int enqueue_factor(ipm_handle* h) {
         const int tb_wgs = (rem - NB) / 64;
         const bool crit_flag = fs && rem > NB && tb_wgs <= 256;
         if (crit_flag) tc.signal = h->d_bulk_done + h->nblk + k;
-        HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
+        if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
+        else HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
         if (!crit_flag) HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
         GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1), as 64x64 sub-tiles
-        HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(uc, sm)));
+        if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));      // 10 sub-tiles of 32x32
+        else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(uc, sm)));
         if (!crit_flag) HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
         if (rem > NB) {
             GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
-            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; }
+            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; }   // 4 workgroups in either variant
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
             if (fs) {

@@ -622,14 +622,17 @@ static int enqueue_factor(ipm_handle* h) {
         // one event per step on the main stream (after the critical panel rows): every extra record / wait
         // costs the pivot chain ~6-12 us of command-processor time (profiles/, trace of a step)
         GemmNT tc = t; tc.M = NB;                                   // critical panel rows: block row k+1
-        if (k >= 1) {
-            if (fs && bulk_wgs[k - 1] > 0) { tc.wait_on = h->d_bulk_done + (k - 1); tc.wait_count = bulk_wgs[k - 1]; }
-            else if (!fs) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[k - 1], 0));
+        if (k >= 1) {     // the previous bulk update either signalled a counter (small grids) or recorded an event
+            if (bulk_wgs[k - 1] > 0) { tc.wait_on = h->d_bulk_done + (k - 1); tc.wait_count = bulk_wgs[k - 1]; }
+            else HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[k - 1], 0));
         }
         // bulk side: the (small) panel launch of the bulk stream polls the completion counter of the critical
         // panel launch instead of a stream event, unless it is large enough to crowd the CUs while it spins
         const int tb_wgs = (rem - NB) / 64;
-        const bool crit_flag = fs && rem > NB && tb_wgs <= 256;
+        // SAFETY: a polling launch holds LDS on every CU it lands on; potrf_diag needs a CU with 133 KB free and
+        // sits upstream of the signal, so a wide poller deadlocks the chain until its spin bound expires
+        // (observed at m = 16384 with 254 pollers).  Only launches that leave most CUs untouched may poll.
+        const bool crit_flag = fs && rem > NB && tb_wgs <= 64;
         if (crit_flag) tc.signal = h->d_bulk_done + h->nblk + k;
         if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
         else HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
@@ -643,9 +646,11 @@ static int enqueue_factor(ipm_handle* h) {
             if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; }   // 4 workgroups in either variant
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
-            if (fs) {
-                int nt = rem / NB;
-                bulk_wgs[k] = (unsigned)(nt * (nt + 1) / 2 - 1);
+            const int nt = rem / NB, ub_wgs = nt * (nt + 1) / 2 - 1;
+            // the per-workgroup release (L2 write-back) of the counter protocol only pays in the latency-bound
+            // regime; a throughput-bound update (thousands of tiles: 16k: 40 -> 50 ms) keeps the stream event
+            if (fs && ub_wgs <= 1024) {
+                bulk_wgs[k] = (unsigned)ub_wgs;
                 ub.signal = h->d_bulk_done + k;
             }
             HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));

@@ -37,9 +37,6 @@ struct ipm_handle {
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
-    bool groups_done_in_factor = false;   // group inverses were enqueued on the third stream inside enqueue_factor
-    hipStream_t stream3 = nullptr;
-    std::vector<hipEvent_t> ev_grp;
     int grouped_trsv = 1;                 // 1024-row group inverses + GEMV solves when nblk % 8 == 0, nblk >= 16
     double *gXT = nullptr, *gX = nullptr, *gS = nullptr, *gPart = nullptr;   // own allocation
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
@@ -285,9 +282,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
     if (h->grouped_trsv && h->nblk % GS == 0 && h->nblk >= 2 * GS) {
         const size_t nG = (size_t)h->nblk / GS;
-        CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-        h->ev_grp.assign(nG, nullptr);
-        for (size_t g = 0; g < nG; ++g) CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp[g], hipEventDisableTiming));
         CREATE_TRY(hipMalloc((void**)&h->gXT, sizeof(double) * nG * GR * GR));
         CREATE_TRY(hipMalloc((void**)&h->gX, sizeof(double) * nG * GR * GR));
         CREATE_TRY(hipMalloc((void**)&h->gS, sizeof(double) * nG * 512 * 512));
@@ -325,8 +319,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
-    for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk, &h->ev_grp})
+    for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -577,7 +570,6 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
 static int enqueue_factor(ipm_handle* h) {
     const int* done = &h->sc->done;
-    h->groups_done_in_factor = false;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     const bool la = h->lookahead != 0 && h->nblk > 2;

@@ -212,25 +212,6 @@ __device__ __forceinline__ void substitute_rows4(double* W, int c0, int r0, int 
     W[(r0 + q) * WLD + c0 + c] = p;
 }
 
-// one row of the panel below tile (c0,c0): v = p * T^{-T} by forward substitution.  Thread-level.
-__device__ __forceinline__ void substitute_row(double* W, int c0, int row, const double* dinv_s) {
-    double p[16];
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-        f64x2 v = *reinterpret_cast<const f64x2*>(&W[row * WLD + c0 + c]);
-        p[c] = v.x; p[c + 1] = v.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        p[k] *= dinv_s[c0 + k];
-#pragma unroll
-        for (int c = k + 1; c < 16; ++c) p[c] = __builtin_fma(-p[k], W[(c0 + c) * WLD + c0 + k], p[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 16; c += 2)
-        *reinterpret_cast<f64x2*>(&W[row * WLD + c0 + c]) = (f64x2){p[c], p[c + 1]};
-}
-
 // T(r0,q0) -= L(r0, c0:c0+16) L(q0, c0:c0+16)^T  (16 x 16 tiles, MFMA).  Wave-level.
 __device__ __forceinline__ void update_tile(double* W, int c0, int r0, int q0, int fr, int fk) {
     f64x4 acc0, acc1 = (f64x4){0.0, 0.0, 0.0, 0.0};

@@ -42,18 +42,6 @@ __global__ void group_diag_transpose_kernel(const double* __restrict__ invD, dou
     for (int j = threadIdx.y; j < 32; j += 8) dst[(int64_t)(bx + j) * GR + by + threadIdx.x] = tile[threadIdx.x][j];
 }
 
-// X_g = XT_g^T for every group.  grid (32, 32, nG), block (32, 8).
-__global__ void group_transpose_kernel(const double* __restrict__ XT, double* X, int g0, const int* done) {
-    if (done && *done) return;
-    __shared__ double tile[32][33];
-    const double* src = XT + (int64_t)(g0 + blockIdx.z) * GR * GR;
-    double* dst = X + (int64_t)(g0 + blockIdx.z) * GR * GR;
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-    for (int j = threadIdx.y; j < 32; j += 8) tile[j][threadIdx.x] = src[(int64_t)(by + j) * GR + bx + threadIdx.x];
-    __syncthreads();
-    for (int j = threadIdx.y; j < 32; j += 8) dst[(int64_t)(bx + j) * GR + by + threadIdx.x] = tile[threadIdx.x][j];
-}
-
 // z[c] -= sum_rc part[rc*np + c], c < np  (fixed order)
 __global__ __launch_bounds__(256) void sub_partials_kernel(double* z, const double* __restrict__ part, int np, int rc,
                                                            const int* done) {

@@ -160,8 +160,10 @@ class IpmSolver:
         self.stats = st.as_dict()
         return self.stats
 
-    def set_profiling(self, on=True):
-        self._check(self._lib.ipm_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, level=2):
+        """0 off, 1 time the A D^2 A^T kernel only, 2 all phases (True == 2 for old callers)."""
+        level = 2 if level is True else (0 if level is False else int(level))
+        self._check(self._lib.ipm_set_profiling(self._h, level))
 
     def phase_ms(self):
         out = (C.c_double * 4)()

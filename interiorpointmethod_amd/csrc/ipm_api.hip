@@ -115,6 +115,11 @@ static const int N_MVEC = 7;    // y b rb t1 t2 dya dy
 static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     Layout L;
     L.mp = round_up(m, NB);
+    {   // the grouped triangular solves (trsv_grouped.h) need whole 1024-row groups: pad a little further when that
+        // costs at most 1/8 more blocks (identity rows are cheap; 4 x nblk dependent launches per iteration are not)
+        const int64_t nb = L.mp / NB, nb8 = round_up(nb, 8);
+        if (nb >= 16 && (nb8 - nb) * 8 <= nb) L.mp = nb8 * NB;
+    }
     L.np = round_up(n, 64);
     L.nblk = (int)(L.mp / NB);
     int64_t c64 = L.mp / 64;

@@ -275,6 +275,29 @@ def test_interior_sparse_drop_in(golden_dir):
     assert ipm.last_info()["iterations"] in (92, 93, 94, 95)
 
 
+def test_reference_named_entry_points(golden_dir):
+    """The host mirror keeps the reference's names and argument meaning (SURVEY 8b seams 1-3)."""
+    z = np.load(os.path.join(golden_dir, "dense_ex3.npz"))
+    obj = ipm.interior(z["A"], z["b"], z["c"], tol=1e-8)                     # main.py:707 (y0 = 0, cap 50000)
+    assert abs(obj - float(z["objective"])) <= 1e-6 * abs(float(z["objective"]))
+    k = np.load(os.path.join(golden_dir, "kat_SC50A.npz"))
+    m, n = (int(v) for v in k["shape"])
+    A = sparse.csc_matrix((k["A_data"], k["A_indices"], k["A_indptr"]), shape=(m, n))
+    x, y, s = k["k0_x"], k["k0_y"], k["k0_s"]
+    dx, dy, ds = ipm.direction_predicted_sparse(A, k["b"], k["c"], x, y, s, method="normal")   # main.py:197
+    assert rel(dx, k["k0_normal_dxa"]) < 1e-10 and rel(dy, k["k0_normal_dya"]) < 1e-10
+    dx, dy, ds = ipm.direction_corrected_sparse(A, k["b"], k["c"], x, y, s, dx, dy, ds)         # main.py:247
+    assert rel(dx, k["k0_dx"]) < 1e-9 and rel(ds, k["k0_ds"]) < 1e-9
+    with pytest.raises(ValueError):
+        ipm.direction_predicted_sparse(A, k["b"], k["c"], x, y, s, method="full")
+    rng = np.random.default_rng(1)
+    M = rng.standard_normal((90, 120))
+    B = M @ M.T
+    rhs = rng.standard_normal((90, 1))
+    zz = ipm.solve_linear(B, rhs)                                                # main.py:176
+    assert zz.shape == (90, 1) and np.linalg.norm(B @ zz - rhs) / np.linalg.norm(rhs) < 1e-10
+
+
 def test_integer_dtype_inputs(golden_dir):
     """the .mat files hold int16/uint8 arrays; the boundary casts to float64."""
     A, b, c = np.array([[3, 6, 8], [8, 4, 1]], dtype=np.int16), np.array([30, 44], dtype=np.uint8), \

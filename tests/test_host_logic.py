@@ -1,0 +1,59 @@
+"""Host-side logic that needs no GPU: the .mat loader (layout of sparse_interior.py:139-216), problem
+validity screening, workload generator pins, and the batch cost model."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+from scipy.io import savemat
+
+from interiorpointmethod_amd import matio, batch
+from interiorpointmethod_amd.workloads import synthetic_lp, flops_per_iteration
+
+
+def _write_mat(path, A, b, f, cTlb, int_dtypes=True):
+    A = sparse.coo_matrix(A)
+    k = A.data.astype(np.int16) if int_dtypes else A.data
+    st = np.zeros((1, 1), dtype=[("i", "O"), ("j", "O"), ("k", "O")])
+    st["i"][0, 0] = A.row.reshape(1, -1).astype(np.uint16)
+    st["j"][0, 0] = A.col.reshape(1, -1).astype(np.uint16)
+    st["k"][0, 0] = k.reshape(1, -1)
+    savemat(path, {"A": st, "b": np.asarray(b).reshape(-1, 1), "f": np.asarray(f).reshape(-1, 1),
+                   "cTlb": np.array([[cTlb]]), "num_variables": np.array([[A.shape[1]]]),
+                   "num_constraints": np.array([[A.shape[0]]])})
+
+
+def test_mat_loader_casts_and_keeps_shape(tmp_path):
+    """Keys f, b, cTlb, A{i,j,k}, num_variables, num_constraints (sparse_interior.py:157-167); integer
+    payloads come back as float64; a trailing empty column keeps the declared shape instead of
+    the max-index inference of sparse_interior.py:215."""
+    A = np.array([[3, 6, 8, 0], [8, 4, 1, 0]])
+    _write_mat(os.path.join(tmp_path, "TOY.mat"), A, np.array([30, 44], dtype=np.uint8),
+               np.array([-100, -125, -20, 0], dtype=np.int16), 2.5)
+    As, b, c, cTlb = matio.create_problem_from_mps("TOY", root=str(tmp_path))
+    assert sparse.issparse(As) and As.shape == (2, 4) and As.dtype == np.float64
+    assert b.shape == (2, 1) and c.shape == (4, 1) and b.dtype == np.float64 and c.dtype == np.float64
+    assert np.array_equal(As.toarray(), A.astype(float)) and cTlb == 2.5
+    assert matio.is_valid_problem(As, b, c)
+    assert not matio.is_valid_problem(As, np.array([[np.inf], [1.0]]), c)
+
+
+def test_npz_fixture_roundtrip(golden_dir):
+    A, b, c, cTlb, valid = matio.load_npz_problem(os.path.join(golden_dir, "netlib", "AFIRO.npz"))
+    assert A.shape == (27, 51) and A.nnz == 102 and valid and b.shape == (27, 1) and c.shape == (51, 1)
+
+
+def test_synthetic_workload_pins():
+    """Sanity pins of SURVEY.md 8(d)."""
+    A, b, c = synthetic_lp(64, 128, seed=0)
+    assert A[0, 0] == 0.1257302210933933
+    assert np.isclose(b[0, 0], 7.898903583954942, rtol=1e-14) and np.isclose(c[0, 0], 13.513107422440132, rtol=1e-14)
+    assert flops_per_iteration(4096, 8192) == pytest.approx(1.608e11, rel=1e-3)
+    assert flops_per_iteration(16384, 32768) == pytest.approx(1.027e13, rel=1e-3)
+
+
+def test_record_layout_and_summary():
+    assert batch.RECORD_FIELDS[:4] == ("id", "status", "iterations", "objective") and batch.NF == 9
+    rec = np.array([[0, 1, 10, 1.0, 0, 0, 0, 0.1, 2], [1, 3, 5, np.nan, 0, 0, 0, 0.2, 0], [2, -6, 0, np.nan, 0, 0, 0, 0.0, 0]])
+    s = batch.summarize(rec)
+    assert (s["converged"], s["nan"], s["invalid"], s["total_iterations"], s["pivots_fixed"]) == (1, 1, 1, 15, 2)

@@ -58,6 +58,7 @@ struct GemmNT {
     unsigned* signal;           // may be null
     const unsigned* wait_on;    // may be null
     unsigned wait_count;
+    unsigned* timeout;          // set to 1 when the bounded poll gave up (surfaced as an error by the host)
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -91,7 +92,10 @@ void gemm_nt_f64_kernel(GemmNT g) {
             unsigned spins = 0;
             while (__hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 24)) break;        // give up (results then fail the parity checks, no hang)
+                if (++spins > (1u << 24)) {             // give up: no hang; the host reports the failure
+                    if (g.timeout) __hip_atomic_store(g.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -42,6 +42,7 @@ struct ipm_handle {
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
     unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
+    int bulk_variant = 0;                 // 1: BK=32 tiles for the bulk trailing update (measured slower: 2.38 vs 2.26 ms)
     int crit_variant = 1;                 // smaller tiles / deeper K steps for the two critical-path GEMMs
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
@@ -302,6 +303,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipMemset(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
+    if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -620,7 +622,7 @@ static int enqueue_factor(ipm_handle* h) {
         // costs the pivot chain ~6-12 us of command-processor time (profiles/, trace of a step)
         GemmNT tc = t; tc.M = NB;                                   // critical panel rows: block row k+1
         if (k >= 1) {     // the previous bulk update either signalled a counter (small grids) or recorded an event
-            if (bulk_wgs[k - 1] > 0) { tc.wait_on = h->d_bulk_done + (k - 1); tc.wait_count = bulk_wgs[k - 1]; }
+            if (bulk_wgs[k - 1] > 0) { tc.wait_on = h->d_bulk_done + (k - 1); tc.wait_count = bulk_wgs[k - 1]; tc.timeout = h->d_flags + 2 * (size_t)h->nblk; }
             else HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[k - 1], 0));
         }
         // bulk side: the (small) panel launch of the bulk stream polls the completion counter of the critical
@@ -640,7 +642,7 @@ static int enqueue_factor(ipm_handle* h) {
         if (!crit_flag) HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
         if (rem > NB) {
             GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
-            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; }   // 4 workgroups in either variant
+            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; tb.timeout = h->d_flags + 2 * (size_t)h->nblk; }   // 4 workgroups in either variant
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
             const int nt = rem / NB, ub_wgs = nt * (nt + 1) / 2 - 1;
@@ -650,7 +652,8 @@ static int enqueue_factor(ipm_handle* h) {
                 bulk_wgs[k] = (unsigned)ub_wgs;
                 ub.signal = h->d_bulk_done + k;
             }
-            HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
+            if (h->bulk_variant == 1) HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
+            else HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
         }
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }
@@ -823,7 +826,7 @@ static int read_scalars(ipm_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->h_sc, h->sc, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&tmo, h->d_flags + 2 * (size_t)h->nblk, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (tmo) return fail(h, IPM_ERR_HIP, "persistent triangular solve timed out waiting for a hand-off (workgroups not co-resident?)");
+    if (tmo) return fail(h, IPM_ERR_HIP, "a device-side hand-off poll timed out (Cholesky look-ahead counters / persistent solve)");
     return IPM_OK;
 }
 

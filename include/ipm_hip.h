@@ -105,7 +105,12 @@ const char* ipm_last_error(const ipm_handle* h);   /* also valid with h == NULL 
 int ipm_set_A_dense(ipm_handle* h, const double* A, int64_t ld, int is_device);
 /* CSC triplets as scipy.sparse.csc_matrix holds them (sparse_interior.py:215); host memory.
  * Duplicate entries are summed (scipy's constructor semantics).  On a sparse handle A stays sparse
- * (SpMV + sparse formation of A D^2 A^T); on a dense handle it is scattered into the dense image. */
+ * (SpMV + sparse formation of A D^2 A^T); on a dense handle it is scattered into the dense image.
+ * A sparse handle also derives the 128-row-block ENVELOPE of A A^T from the structure of A in the row order
+ * given: blocks below it are structurally zero in B and stay zero in the factor, and the blocked Cholesky
+ * and the triangular solves skip them (exact; environment IPM_ENVELOPE=0 disables).  The row order that makes
+ * the envelope small is the caller's choice -- the Python host applies reverse Cuthill-McKee to the pattern of
+ * A A^T when that pays (SuperLU behind the reference's spsolve reorders too, main.py:180). */
 int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t* rowind,
                   const double* val, int64_t nnz);
 int ipm_set_bc(ipm_handle* h, const double* b, const double* c);        /* host, length m / n */

@@ -59,6 +59,13 @@ struct ipm_handle {
     double *y = nullptr, *b = nullptr, *rb = nullptr, *t1 = nullptr, *t2 = nullptr, *dya = nullptr, *dy = nullptr;
     double *atp = nullptr, *part = nullptr, *slab = nullptr;
     int form_variant = 0;
+    // Tile envelope (skyline) of A A^T for sparse handles, from the structure of A in the caller's row order:
+    // env_last[k] = last 128-row block with a structural nonzero at or left of column block k (monotone).  Blocks
+    // below it are exactly zero in B and stay zero in L, so the panel solves, trailing updates and triangular
+    // solves skip them.  The Python host reorders the rows (reverse Cuthill-McKee) to make the envelope small.
+    std::vector<int> env_last, env_first;     // env_first[i] = first column block with env_last >= i
+    bool use_env = false;
+    int envelope = 1;                         // IPM_ENVELOPE=0 disables
     bool sparse = false;                 // A kept as CSR + CSC on the device
     int64_t nnz_cap = 0, nnz = 0;
     int* d_tile_order = nullptr;         // 2-D patch order of the lower 128x128 tiles of B (L2 reuse)
@@ -277,6 +284,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->d_colind = (int*)(base + L.off_colind); h->d_rowind = (int*)(base + L.off_rowind);
     h->d_rval = (double*)(base + L.off_rval); h->d_cval = (double*)(base + L.off_cval);
     if (const char* e = getenv("IPM_FORM_VARIANT")) h->form_variant = atoi(e);
+    if (const char* e = getenv("IPM_ENVELOPE")) h->envelope = atoi(e);
     // zero everything except A and B (padding entries of every vector must stay 0)
     CREATE_TRY(hipMemsetAsync(base + L.off_inv, 0, L.off_slab - L.off_inv, h->stream));
     CREATE_TRY(hipHostMalloc((void**)&h->h_sc, sizeof(Scalars), hipHostMallocDefault));
@@ -408,6 +416,22 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
             HIP_TRY(h, hipMemcpyAsync(h->d_rval, rv.data(), sizeof(double) * nz, hipMemcpyHostToDevice, h->stream));
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        {   // tile envelope of A A^T: B(i,k) != 0 structurally iff some column of A has rows in blocks i and k
+            std::vector<int> last(h->nblk);
+            for (int k = 0; k < h->nblk; ++k) last[k] = k;
+            for (int64_t j = 0; j < h->n; ++j) {
+                if (cp[j + 1] == cp[j]) continue;
+                const int top = ri[cp[j + 1] - 1] / NB;                 // rows are sorted within a column
+                for (int q = cp[j]; q < cp[j + 1]; ++q) { int kb = ri[q] / NB; if (last[kb] < top) last[kb] = top; }
+            }
+            for (int k = 1; k < h->nblk; ++k) if (last[k] < last[k - 1]) last[k] = last[k - 1];
+            std::vector<int> first(h->nblk);
+            for (int i = 0, c = 0; i < h->nblk; ++i) { while (last[c] < i) ++c; first[i] = c; }
+            double work = 0.0, dense = 0.0;
+            for (int k = 0; k < h->nblk; ++k) { double w = last[k] - k, d = h->nblk - 1 - k; work += w * w; dense += d * d; }
+            h->env_last = last; h->env_first = first;
+            h->use_env = h->envelope != 0 && work < 0.8 * dense;         // only when it actually removes work
+        }
         h->nnz = nz; h->haveA = true; h->predictor_valid = false;
         return IPM_OK;
     }
@@ -575,8 +599,9 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 //   main stream : potrf_diag(k) -> [wait bulk(k-1)] -> panel rows of block k+1 -> update of tile (k+1,k+1)
 //   bulk stream : [wait diag(k)] panel rows >= k+2 -> [wait crit(k)] rest of the trailing update
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
-static int enqueue_factor(ipm_handle* h) {
+static int enqueue_factor(ipm_handle* h, bool use_env = false) {
     const int* done = &h->sc->done;
+    use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     const bool la = h->lookahead != 0 && h->nblk > 2;
@@ -602,6 +627,13 @@ static int enqueue_factor(ipm_handle* h) {
         }
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
         if (rem <= 0) break;
+        if (use_env) {                                              // rows below the envelope are zero and stay zero
+            rem = std::min(rem, (h->env_last[k] - k) * NB);
+            if (rem <= 0) {                                         // nothing below the diagonal block in this column
+                if (la) HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
+                continue;
+            }
+        }
         double* panel = h->B + (int64_t)(k + 1) * NB * h->mp + (int64_t)k * NB;
         GemmNT t = gemm_defaults();                                 // L_ik = B_ik inv(L_kk)^T, in place
         t.tile_order = nullptr; t.batch = 1; t.sP = t.sQ = t.sC = 0; t.batch2 = 1; t.sP2 = t.sQ2 = t.sC2 = 0;
@@ -712,6 +744,7 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out) {
     for (int g = 0; g < nG; ++g) {                                        // forward: L z = r
         launch_dense_gemv_n(h, h->gX + (int64_t)g * GR * GR, GR, GR, GR, r + (int64_t)g * GR, 1.0, 0.0, nullptr, z + (int64_t)g * GR);
         int below = (int)(h->mp - (int64_t)(g + 1) * GR);
+        if (h->use_env) below = std::min(below, (int)((int64_t)(h->env_last[(g + 1) * GS - 1] + 1) * NB - (int64_t)(g + 1) * GR));
         if (below > 0) {
             double* rb = r + (int64_t)(g + 1) * GR;
             launch_dense_gemv_n(h, h->B + (int64_t)(g + 1) * GR * h->mp + (int64_t)g * GR, h->mp, below, GR, z + (int64_t)g * GR, -1.0, 1.0,
@@ -721,11 +754,13 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out) {
     for (int g = nG - 1; g >= 0; --g) {                                   // backward: L^T w = z
         launch_dense_gemv_n(h, h->gXT + (int64_t)g * GR * GR, GR, GR, GR, z + (int64_t)g * GR, 1.0, 0.0, nullptr, out + (int64_t)g * GR);
         int left = g * GR;
+        const int c0 = h->use_env ? std::min(left, h->env_first[g * GS] * NB) : 0;   // columns left of c0 are zero in these rows
+        left -= c0;
         if (left > 0) {
             dim3 grid((unsigned)((left + 511) / 512), 16);
-            hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->B + (int64_t)g * GR * h->mp, h->mp, GR / 16, left,
+            hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->B + (int64_t)g * GR * h->mp + c0, h->mp, GR / 16, left,
                                out + (int64_t)g * GR, h->gPart, done);
-            hipLaunchKernelGGL(sub_partials_kernel, dim3((unsigned)((left + 255) / 256)), dim3(256), 0, h->stream, z, h->gPart, left, 16, done);
+            hipLaunchKernelGGL(sub_partials_kernel, dim3((unsigned)((left + 255) / 256)), dim3(256), 0, h->stream, z + c0, h->gPart, left, 16, done);
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -751,14 +786,17 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out) {
     TrsvStep a;
     a.L = h->B; a.ld = h->mp; a.inv = h->invD; a.done = &h->sc->done;
     a.r = r; a.z = h->t2;
+    a.j0 = 0;
     for (int k = 0; k < h->nblk; ++k) {
         a.k = k;
-        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(h->nblk - k), dim3(256), 0, h->stream, a);
+        const int nb = h->use_env ? h->env_last[k] - k + 1 : h->nblk - k;
+        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb), dim3(256), 0, h->stream, a);
     }
     a.r = h->t2; a.z = out;
     for (int k = h->nblk - 1; k >= 0; --k) {
         a.k = k;
-        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k + 1), dim3(256), 0, h->stream, a);
+        a.j0 = h->use_env ? h->env_first[k] : 0;
+        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k - a.j0 + 1), dim3(256), 0, h->stream, a);
     }
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
@@ -811,7 +849,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     if ((rc = enqueue_form(h, h->d))) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-    if ((rc = enqueue_factor(h))) return rc;
+    if ((rc = enqueue_factor(h, true))) return rc;
     if ((rc = enqueue_group_inverses(h))) return rc;
     if (all) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
     if ((rc = enqueue_predictor(h, all ? ev + 4 : nullptr))) return rc;
@@ -856,7 +894,7 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
         hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
         if ((rc = enqueue_residuals(h))) return rc;
         if ((rc = enqueue_form(h, h->d))) return rc;
-        if ((rc = enqueue_factor(h))) return rc;
+        if ((rc = enqueue_factor(h, true))) return rc;
         if ((rc = enqueue_group_inverses(h))) return rc;
         if ((rc = enqueue_predictor(h, nullptr))) return rc;
         VecArgs a = vec_args(h);
@@ -1006,10 +1044,13 @@ extern "C" int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, con
     HIP_TRY(h, hipMemcpyAsync(h->B, img.data(), sizeof(double) * mp * mp, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->t1, 0, sizeof(double) * mp, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->t1, rhs, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+    const bool saved_env = h->use_env;
+    h->use_env = false;                                   // an arbitrary dense B: no structure to exploit
     int rc = enqueue_factor(h);
+    if (!rc) rc = enqueue_group_inverses(h);
+    if (!rc) rc = enqueue_potrs(h, h->t1, h->dy);
+    h->use_env = saved_env;
     if (rc) return rc;
-    if ((rc = enqueue_group_inverses(h))) return rc;
-    if ((rc = enqueue_potrs(h, h->t1, h->dy))) return rc;
     HIP_TRY(h, hipMemcpyAsync(z, h->dy, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
     if ((rc = read_scalars(h))) return rc;
     if (pivots_fixed) *pivots_fixed = h->h_sc->fixed;

@@ -488,6 +488,7 @@ struct TrsvStep {
     double* r;                       // running right-hand side (consumed)
     double* z;                       // solution
     int k;                           // block step
+    int j0;                          // backward step: first column block with a structural nonzero in block row k
     const int* done;
 };
 
@@ -515,14 +516,14 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(TrsvStep a) {
     if (tid < NB) a.r[(int64_t)i * NB + tid] -= us[tid];
 }
 
-// backward step k (descending): w_k = inv(L_kk)^T z_k ; z_j -= L_kj^T w_k for j < k. grid = k+1.
+// backward step k (descending): w_k = inv(L_kk)^T z_k ; z_j -= L_kj^T w_k for j0 <= j < k. grid = k-j0+1.
 // Block j == k writes w_k to `z` (the solution); blocks j < k update the running rhs `r`.
 __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) {
     if (a.done && *a.done) return;
     __shared__ double vs[NB], ws[NB], us[NB];
     __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
     const int tid = threadIdx.x;
-    const int j = blockIdx.x;
+    const int j = a.j0 + blockIdx.x;
     BlockRegs RI, RL;
     block_load(RI, a.inv + (int64_t)a.k * NB * NB, NB);
     if (j != a.k) block_load(RL, a.L + (int64_t)a.k * NB * a.ld + (int64_t)j * NB, a.ld);

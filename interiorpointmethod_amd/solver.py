@@ -34,6 +34,37 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+REORDER_MIN_ROWS = 2048      # below this the factorization is a latency chain; reordering buys nothing
+
+
+def _tile_envelope_work(P, nb=128):
+    """Sum over 128-column blocks of (envelope height in blocks)^2 for the symmetric pattern P: the work measure the
+    blocked Cholesky in libipm_hip pays (it skips the blocks below the tile envelope)."""
+    P = P.tocoo()
+    nblk = (P.shape[0] + nb - 1) // nb
+    last = np.arange(nblk)
+    np.maximum.at(last, np.minimum(P.row, P.col) // nb, np.maximum(P.row, P.col) // nb)
+    last = np.maximum.accumulate(last)
+    return float(np.sum((last - np.arange(nblk)) ** 2)), float(np.sum((nblk - 1 - np.arange(nblk)) ** 2))
+
+
+def envelope_row_order(A, force=False):
+    """Reverse Cuthill-McKee order of the rows of A on the pattern of A A^T, or None when it does not shrink the
+    tile envelope of the normal matrix by at least 30 % (force=True: always the RCM order).  The row order of A is the caller's to choose: y and dy are
+    permuted back, x and s are untouched, so the solver seam is unchanged (the reference's SuperLU also reorders
+    internally, COLAMD, main.py:180)."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    P = abs(A) @ abs(A).T
+    P = _sp.csr_matrix(P)
+    P.data[:] = 1.0
+    perm = np.asarray(reverse_cuthill_mckee(P, symmetric_mode=True), dtype=np.int64)
+    before, dense = _tile_envelope_work(P)
+    after, _ = _tile_envelope_work(P[perm][:, perm])
+    if force or after < 0.7 * min(before, dense):
+        return perm
+    return None
+
+
 def _col(v, n, name):
     v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
     if v.shape[0] != n:
@@ -45,10 +76,11 @@ class IpmSolver:
     """One LP bound to one GPU: owns a libipm_hip handle whose workspace is a torch tensor."""
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
-                 check_every=4, use_torch=True, dense=False, regularize=0.0):
+                 check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto"):
         lib = _lib.load()
         self._lib = lib
         self._h = None
+        self._perm = None          # device row i = caller's row perm[i] (sparse A with a profitable RCM order only)
         if _sp is not None and _sp.issparse(A):
             A = _sp.csc_matrix(A, dtype=np.float64)
             A.sum_duplicates()
@@ -64,6 +96,13 @@ class IpmSolver:
         self.m, self.n = int(m), int(n)
         b = _col(b, self.m, "b")
         c = _col(c, self.n, "c")
+        if _sp is not None and _sp.issparse(A) and reorder and (reorder == "rcm" or self.m >= REORDER_MIN_ROWS):
+            perm = envelope_row_order(A, force=(reorder == "rcm"))     # "auto": only when it pays
+            if perm is not None:
+                self._perm = perm
+                A = _sp.csc_matrix(_sp.csr_matrix(A)[perm])
+                A.sort_indices()
+                b = np.ascontiguousarray(b[perm])
         opts = _lib.Options()
         lib.ipm_default_options(C.byref(opts))
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
@@ -129,14 +168,24 @@ class IpmSolver:
     def init_state(self, y0=1.0):
         self._check(self._lib.ipm_init_state(self._h, float(y0)))
 
+    def _rows_in(self, v):          # caller's row order -> device row order
+        return v if self._perm is None else np.ascontiguousarray(v[self._perm])
+
+    def _rows_out(self, v):         # device row order -> caller's row order
+        if self._perm is None:
+            return v
+        out = np.empty_like(v)
+        out[self._perm] = v
+        return out
+
     def set_state(self, x, y, s):
-        x, y, s = _col(x, self.n, "x"), _col(y, self.m, "y"), _col(s, self.n, "s")
+        x, y, s = _col(x, self.n, "x"), self._rows_in(_col(y, self.m, "y")), _col(s, self.n, "s")
         self._check(self._lib.ipm_set_state(self._h, _dptr(x), _dptr(y), _dptr(s)))
 
     def get_state(self):
         x, y, s = np.empty(self.n), np.empty(self.m), np.empty(self.n)
         self._check(self._lib.ipm_get_state(self._h, _dptr(x), _dptr(y), _dptr(s)))
-        return x.reshape(-1, 1), y.reshape(-1, 1), s.reshape(-1, 1)
+        return x.reshape(-1, 1), self._rows_out(y).reshape(-1, 1), s.reshape(-1, 1)
 
     # -- seams
     def newton_direction(self, corrector=False):
@@ -145,7 +194,7 @@ class IpmSolver:
         self._check(self._lib.ipm_newton_direction(self._h, 1 if corrector else 0, _dptr(dx), _dptr(dy),
                                                    _dptr(ds), C.byref(st)))
         self.stats = st.as_dict()
-        return dx.reshape(-1, 1), dy.reshape(-1, 1), ds.reshape(-1, 1)
+        return dx.reshape(-1, 1), self._rows_out(dy).reshape(-1, 1), ds.reshape(-1, 1)
 
     def iterate(self, n_steps):
         st = _lib.Stats()
@@ -175,14 +224,22 @@ class IpmSolver:
         d = _col(d, self.n, "d")
         B = np.empty((self.m, self.m))
         self._check(self._lib.ipm_form_normal_matrix(self._h, _dptr(d), _dptr(B), self.m))
+        if self._perm is not None:
+            out = np.empty_like(B)
+            out[np.ix_(self._perm, self._perm)] = B
+            return out
         return B
 
     def get_factor(self):
+        """Lower Cholesky factor of the current normal matrix in DEVICE row order (rows self._perm of the caller's
+        A when a reordering was applied)."""
         L = np.empty((self.m, self.m))
         self._check(self._lib.ipm_get_factor(self._h, _dptr(L), self.m))
         return L
 
     def solve_linear(self, B, rhs):
+        if self._perm is not None:
+            raise ValueError("solve_linear on a handle with reordered rows: create the solver with reorder=None")
         B = np.ascontiguousarray(np.asarray(B, dtype=np.float64))
         rhs = _col(rhs, self.m, "rhs")
         z = np.empty(self.m)

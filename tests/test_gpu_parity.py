@@ -152,6 +152,61 @@ def test_sparse_and_dense_paths_agree(golden_dir, name):
     assert st1["objective"] == st1b["objective"] and st1["iterations"] == st1b["iterations"]   # reproducible
 
 
+@pytest.mark.parametrize("name", ["SC50A", "BANDM", "SCSD6"])
+def test_reordered_rows_same_seam(golden_dir, name):
+    """reorder="rcm" permutes the rows of A on the device (smaller tile envelope of A A^T); the seam must not
+    notice: B, directions (dy un-permuted), iterates and the solve agree with the natural order."""
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    rng = np.random.default_rng(5)
+    d = 10.0 ** rng.uniform(-3, 3, A.shape[1])
+    with ipm.IpmSolver(A, b, c, reorder=None) as nat, ipm.IpmSolver(A, b, c, reorder="rcm") as rcm:
+        assert nat._perm is None and sorted(rcm._perm.tolist()) == list(range(A.shape[0]))
+        assert rel(rcm.form_normal_matrix(d), nat.form_normal_matrix(d)) < 1e-13
+        nat.init_state(1.0); rcm.init_state(1.0)
+        for u, v in zip(rcm.newton_direction(False), nat.newton_direction(False)):
+            assert rel(u, v) < 1e-9
+        y0 = rng.standard_normal(A.shape[0])
+        x0 = rng.uniform(0.5, 2, A.shape[1]); s0 = rng.uniform(0.5, 2, A.shape[1])
+        nat.set_state(x0, y0, s0); rcm.set_state(x0, y0, s0)
+        assert np.array_equal(rcm.get_state()[1].ravel(), y0)              # round trip through the permutation
+        nat.iterate(1); rcm.iterate(1)
+        for u, v in zip(rcm.get_state(), nat.get_state()):
+            assert rel(u, v) < 1e-9
+        nat.init_state(1.0); rcm.init_state(1.0)
+        s1, s2 = rcm.solve(tol=1e-8, max_iter=500), nat.solve(tol=1e-8, max_iter=500)
+    assert s1["status"] == 1 and s2["status"] == 1
+    assert abs(s1["objective"] - s2["objective"]) <= 1e-8 * max(1.0, abs(s2["objective"]))
+
+
+def test_tile_envelope_skips_only_zeros():
+    """Block-bidiagonal A (staircase LP, 2500 rows): A A^T is block tridiagonal, so its tile envelope is 2-3 blocks of
+    20 and the factorization / triangular solves skip the rest.  The direction must equal the dense path's (which
+    skips nothing) and IPM_ENVELOPE=0 on the same handle type."""
+    rng = np.random.default_rng(11)
+    nbk, bs, cs = 25, 100, 160
+    blocks = [[None] * nbk for _ in range(nbk)]
+    for i in range(nbk):
+        blocks[i][i] = sparse.random(bs, cs, density=0.05, random_state=np.random.RandomState(i), format="csr") + \
+            sparse.eye(bs, cs, format="csr")
+        if i + 1 < nbk:
+            blocks[i + 1][i] = sparse.random(bs, cs, density=0.02, random_state=np.random.RandomState(100 + i), format="csr")
+    A = sparse.csc_matrix(sparse.bmat(blocks))
+    m, n = A.shape
+    x0 = rng.uniform(0.5, 1.5, n); y0 = rng.standard_normal(m); s0 = rng.uniform(0.5, 1.5, n)
+    b, c = A @ x0, A.T @ y0 + s0
+    with ipm.IpmSolver(A, b, c, reorder=None) as sp_, ipm.IpmSolver(A, b, c, dense=True) as de_:
+        assert sp_.sparse
+        sp_.init_state(1.0); de_.init_state(1.0)
+        for u, v in zip(sp_.newton_direction(False), de_.newton_direction(False)):
+            assert rel(u, v) < 1e-10
+        L1, L2 = sp_.get_factor(), de_.get_factor()
+        assert rel(L1, L2) < 1e-10
+        assert np.count_nonzero(L1[1000:, :300]) == 0                       # far below the envelope: never touched
+        st1, st2 = sp_.solve(tol=1e-8, max_iter=200), de_.solve(tol=1e-8, max_iter=200)
+    assert st1["status"] == 1 and st1["iterations"] == st2["iterations"]
+    assert abs(st1["objective"] - st2["objective"]) <= 1e-9 * max(1.0, abs(st2["objective"]))
+
+
 # ------------------------------------------------------------------ direction seam vs the reference
 @pytest.mark.parametrize("name", ["AFIRO", "SC50A", "BANDM"])
 def test_direction_kats(golden_dir, name):

@@ -57,3 +57,26 @@ def test_record_layout_and_summary():
     rec = np.array([[0, 1, 10, 1.0, 0, 0, 0, 0.1, 2], [1, 3, 5, np.nan, 0, 0, 0, 0.2, 0], [2, -6, 0, np.nan, 0, 0, 0, 0.0, 0]])
     s = batch.summarize(rec)
     assert (s["converged"], s["nan"], s["invalid"], s["total_iterations"], s["pivots_fixed"]) == (1, 1, 1, 15, 2)
+
+
+def test_envelope_row_order_recovers_a_staircase():
+    """Host side of the tile-envelope Cholesky: a block-bidiagonal A with shuffled rows has a dense-looking tile
+    envelope; reverse Cuthill-McKee on the pattern of A A^T brings it back to a narrow band."""
+    from interiorpointmethod_amd import solver as S
+    nbk, bs, cs = 30, 100, 120
+    blocks = [[None] * nbk for _ in range(nbk)]
+    for i in range(nbk):
+        blocks[i][i] = sparse.random(bs, cs, density=0.05, random_state=np.random.RandomState(i), format="csr") + \
+            sparse.eye(bs, cs, format="csr")
+        if i + 1 < nbk:
+            blocks[i + 1][i] = sparse.random(bs, cs, density=0.03, random_state=np.random.RandomState(99 + i), format="csr")
+    A = sparse.csr_matrix(sparse.bmat(blocks))
+    shuffled = A[np.random.default_rng(0).permutation(A.shape[0])]
+    perm = S.envelope_row_order(shuffled)
+    assert perm is not None and sorted(perm.tolist()) == list(range(A.shape[0]))
+    P = abs(shuffled) @ abs(shuffled).T
+    before, dense = S._tile_envelope_work(P)
+    after, _ = S._tile_envelope_work(sparse.csr_matrix(P)[perm][:, perm])
+    assert before > 0.8 * dense and after < 0.15 * dense
+    # a matrix whose normal matrix is dense gains nothing: no reordering
+    assert S.envelope_row_order(sparse.csr_matrix(np.random.default_rng(1).standard_normal((300, 400)))) is None

@@ -387,9 +387,36 @@ def test_dense_4096x8192_full_solve():
     rc = A.T @ y + s - c
     assert np.linalg.norm(rb) / (1 + np.linalg.norm(b)) < 1e-8
     assert np.linalg.norm(rc) / (1 + np.linalg.norm(c)) < 1e-8
-    assert np.all(x > 0) and np.all(s > 0) and float(x.T @ s) <= 1e-8
-    assert abs(float(c.T @ x) - float(b.T @ y)) <= 1e-6 * 3.77e2
+    assert np.all(x > 0) and np.all(s > 0) and (x.T @ s).item() <= 1e-8
+    assert abs((c.T @ x).item() - (b.T @ y).item()) <= 1e-6 * 3.77e2
     assert np.array_equal(x, x2) and st2["iterations"] == st["iterations"]     # bitwise reproducible
+
+
+# ADLITTLE is in the conversion fixtures only: the reference's driver runs it to its 999-iteration cap (the dual residual
+# stalls at 1.5e-3, it never passes the stop test) and just happens to return the optimum from there.
+GENERAL = ["AFIRO", "SC50A", "SC50B", "SHARE2B", "SC105", "STOCFOR1", "BANDM", "KB2"]
+
+
+@pytest.mark.parametrize("name", GENERAL)
+def test_new_interior_sparse_general_form(golden_dir, name):
+    """The general-form driver (main.py:1081-1245) on the reference's benchmarks_full inputs: objective within 1e-6
+    relative of what the reference's own new_interior_sparse returns (tol=1e-8, e3=1e-6).  KB2 (finite upper
+    bounds) does not converge in the reference (it returns 18.49); there the pin is the Netlib optimum."""
+    from interiorpointmethod_amd import general_form as G
+    z = np.load(os.path.join(golden_dir, "general", name + ".npz"))
+
+    def mat(prefix):
+        if prefix + "_none" in z.files:
+            return None
+        return sparse.csc_matrix((z[prefix + "_data"], z[prefix + "_indices"], z[prefix + "_indptr"]),
+                                 shape=tuple(int(v) for v in z[prefix + "_shape"]))
+    obj, info = G.new_interior_sparse(c=z["c"], Aineq=mat("Aineq"), bineq=z["bineq"] if "bineq" in z.files else None,
+                                      Aeq=mat("Aeq"), beq=z["beq"] if "beq" in z.files else None, lb=z["lb"], ub=z["ub"],
+                                      tol=1e-8, return_info=True)
+    want = float(z["netlib_optimum"]) if name == "KB2" else float(z["ref_objective"])
+    assert info["status"] == 1 and info["iterations"] <= 999
+    assert abs(obj - want) <= 1e-6 * max(1.0, abs(want))
+    assert abs(obj - float(z["netlib_optimum"])) <= 1e-6 * max(1.0, abs(float(z["netlib_optimum"])))
 
 
 def test_smoke_entry():

@@ -99,7 +99,7 @@ def netlib_main(args):
     t0 = time.perf_counter()
     rec, _ = batch.run_batch(probs, costs=costs, device=local_rank, dist=dist,
                              gather_device=torch.device("cuda", local_rank) if dist is not None else None,
-                             tol=1e-8, max_iter=300, regularize=args.regularize)
+                             tol=1e-8, max_iter=300, regularize=args.regularize, workers=args.workers)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -114,8 +114,9 @@ def netlib_main(args):
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
                "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
-               "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s), 1 LP per GPU at a time" % (
-                   args.netlib_set, len(names), max(world, 1))},
+               "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s); per GPU the LPs with more than %d rows "
+                                      "one at a time, the others %d at a time on separate streams" % (
+                   args.netlib_set, len(names), max(world, 1), batch.SMALL_ROWS, max(1, args.workers))},
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize,
                "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
                           for r in rec}}
@@ -138,6 +139,7 @@ def main():
     ap.add_argument("--netlib-set", default="all", choices=["all", "parity"],
                     help="all 73 valid files, or the 26 on which the reference converges")
     ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
+    ap.add_argument("--workers", type=int, default=2, help="netlib: small LPs solved concurrently per GPU (1 = strictly one at a time)")
     ap.add_argument("--regularize", type=float, default=0.0, help="netlib: Tikhonov shift (0 = reference-faithful)")
     args = ap.parse_args()
     if args.workload == "netlib":

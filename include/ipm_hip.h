@@ -50,6 +50,16 @@ enum {
     IPM_STATUS_NAN = 3         /* non-finite iterate / residual            main.py:1141-1148 */
 };
 
+/* ipm_options.flags */
+enum {
+    /* The Cholesky look-ahead hands work between its two streams through device counters polled inside kernels.
+     * That is only safe while the handle's streams own their hardware queues: when several handles are driven
+     * concurrently on one GPU (more streams than hardware queues), a polling kernel can sit in front of its own
+     * producer in a shared queue.  Set this flag for such handles: stream events are used instead (slower per
+     * step, never blocks). */
+    IPM_FLAG_NO_DEVICE_POLLING = 1
+};
+
 typedef struct ipm_handle ipm_handle;
 
 typedef struct ipm_options {
@@ -57,7 +67,7 @@ typedef struct ipm_options {
     double pivot_guard_eps;  /* pivot <= eps*max diag(B) -> pivot_guard_big   */
     double pivot_guard_big;  /* replacement pivot, default 1e64 */
     int32_t check_every;     /* iterations enqueued between host status reads (>=1) */
-    int32_t reserved0;
+    int32_t flags;           /* IPM_FLAG_*; 0 = defaults */
     int64_t sparse_nnz;      /* > 0: handle keeps A sparse (CSR+CSC on the device, no dense image) with at
                                 most this many nonzeros; only ipm_set_A_csc may then supply A */
     double regularize;       /* Tikhonov shift: factor B + regularize*max diag(B)*I (0 = off, the default;

@@ -24,6 +24,7 @@ EXPORTS = [
 
 IPM_OK = 0
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NAN = 0, 1, 2, 3
+FLAG_NO_DEVICE_POLLING = 1      # include/ipm_hip.h: IPM_FLAG_NO_DEVICE_POLLING
 ERR_INVALID_INPUT = -6
 
 
@@ -39,7 +40,7 @@ class IpmError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("eta", C.c_double), ("pivot_guard_eps", C.c_double), ("pivot_guard_big", C.c_double),
-                ("check_every", C.c_int32), ("reserved0", C.c_int32), ("sparse_nnz", C.c_int64),
+                ("check_every", C.c_int32), ("flags", C.c_int32), ("sparse_nnz", C.c_int64),
                 ("regularize", C.c_double)]
 
 

@@ -40,7 +40,7 @@ def lpt_partition(costs, world):
     return shards
 
 
-def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0):
+def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, concurrent=False):
     """Solve one LP (A, b, c) on `device` with the HIP path -> dict of statistics."""
     from . import _lib
     from .solver import solve_with_info
@@ -48,7 +48,7 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
     t0 = time.perf_counter()
     try:
         _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device,
-                                        regularize=regularize)
+                                        regularize=regularize, concurrent=concurrent)
         info = dict(info)
     except _lib.IpmError as e:
         nan = float("nan")
@@ -58,16 +58,58 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
     return info
 
 
-def solve_shard(problems, ids, device=0, solve_fn=solve_one, **kw):
-    """Solve problems[i] for i in ids on this rank's GPU -> (len(ids), NF) float64 records."""
+def _in_own_stream(solve_fn, problem, device, kw):
+    """Run solve_fn with a torch stream of its own as the thread's current stream (a handle binds to the current
+    stream), so solves issued from different host threads overlap on the GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
+                return solve_fn(problem, device=device, **kw)
+    except ImportError:
+        pass
+    return solve_fn(problem, device=device, **kw)
+
+
+SMALL_ROWS = 1 << 30    # LPs up to this many rows share the GPU with each other (all of them; lower it to serialise the largest)
+
+
+def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
+    """Solve problems[i] for i in ids on this rank's GPU -> (len(ids), NF) float64 records.
+
+    workers > 1: the LPs with at most SMALL_ROWS rows are solved `workers` at a time from host threads, each
+    handle on its own stream.  A small LP is a chain of ~60 launch-bound kernels per iteration that uses a few
+    CUs, so several of them interleave on one GPU almost for free; results do not depend on the interleaving (every
+    handle is independent and deterministic).  Such handles are created with IPM_FLAG_NO_DEVICE_POLLING: HIP maps
+    streams onto a few hardware queues, and a kernel that polls for a counter can end up queued in front of its own
+    producer (measured: 3.3 s poll timeouts).  Larger LPs run one at a time first, with the polling hand-offs."""
     rec = np.zeros((len(ids), NF), dtype=np.float64)
-    for row, i in enumerate(ids):
+
+    def one(row_i):
+        row, i = row_i
         t0 = time.perf_counter()
-        info = dict(solve_fn(problems[i], device=device, **kw))
+        if workers > 1 and problems[i][0].shape[0] <= SMALL_ROWS:
+            # handles that share the GPU must not poll on the device (IPM_FLAG_NO_DEVICE_POLLING, include/ipm_hip.h)
+            info = dict(_in_own_stream(solve_fn, problems[i], device, dict(kw, concurrent=True) if solve_fn is solve_one else kw))
+        else:
+            info = dict(solve_fn(problems[i], device=device, **kw))
         info.setdefault("seconds", time.perf_counter() - t0)
         rec[row] = [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]),
                     float(info["rp"]), float(info["rd"]), float(info["gap"]), float(info["seconds"]),
                     float(info["pivots_fixed"])]
+
+    rows = list(enumerate(ids))
+    if workers <= 1:
+        for r in rows:
+            one(r)
+        return rec
+    from concurrent.futures import ThreadPoolExecutor
+    size = lambda r: problems[r[1]][0].shape[0]                     # noqa: E731
+    for r in [r for r in rows if size(r) > SMALL_ROWS]:
+        one(r)
+    small = sorted([r for r in rows if size(r) <= SMALL_ROWS], key=lambda r: (-size(r), r[1]))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(one, small))
     return rec
 
 
@@ -91,7 +133,7 @@ def gather_records(local, shard_sizes, dist=None, device=None):
     return out[np.argsort(out[:, 0], kind="stable")]
 
 
-def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, **kw):
+def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1, **kw):
     """Shard `problems` (list of (A, b, c)) over the ranks of `dist`, solve, gather statistics.
 
     Returns (records sorted by id, this rank's wall seconds).  Without an initialised process
@@ -102,7 +144,7 @@ def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, sol
         costs = [predicted_cost(p[0].shape[0], p[0].shape[1]) for p in problems]
     shards = lpt_partition(costs, world)
     t0 = time.perf_counter()
-    local = solve_shard(problems, shards[rank], device=device, solve_fn=solve_fn, **kw)
+    local = solve_shard(problems, shards[rank], device=device, solve_fn=solve_fn, workers=workers, **kw)
     seconds = time.perf_counter() - t0
     records = gather_records(local, [len(s) for s in shards], dist=dist if world > 1 else None,
                              device=gather_device)

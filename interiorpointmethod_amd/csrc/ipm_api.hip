@@ -310,6 +310,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipMalloc((void**)&h->d_bulk_done, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));   // [0,nblk) bulk, [nblk,2nblk) crit
     CREATE_TRY(hipMemset(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
     if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
+    if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }

@@ -76,7 +76,7 @@ class IpmSolver:
     """One LP bound to one GPU: owns a libipm_hip handle whose workspace is a torch tensor."""
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
-                 check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto"):
+                 check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto", concurrent=False):
         lib = _lib.load()
         self._lib = lib
         self._h = None
@@ -108,6 +108,7 @@ class IpmSolver:
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
         opts.check_every = int(check_every)
         opts.regularize = float(regularize)
+        opts.flags = _lib.FLAG_NO_DEVICE_POLLING if concurrent else 0     # several handles at once on one GPU
         nbytes = C.c_size_t(0)
         self.sparse = _sp is not None and _sp.issparse(A)
         if self.sparse:                      # A stays sparse on the device (CSR + CSC, sparse formation of B)

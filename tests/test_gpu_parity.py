@@ -419,6 +419,19 @@ def test_new_interior_sparse_general_form(golden_dir, name):
     assert abs(obj - float(z["netlib_optimum"])) <= 1e-6 * max(1.0, abs(float(z["netlib_optimum"])))
 
 
+def test_batch_two_at_a_time_same_records(golden_dir):
+    """Batched mode with two LPs in flight per GPU (host threads, own streams, IPM_FLAG_NO_DEVICE_POLLING): the
+    records equal the one-at-a-time run bit for bit -- only the synchronisation mechanism differs."""
+    from interiorpointmethod_amd import batch
+    names = ["AFIRO", "SC50A", "BANDM", "SCSD6", "SHARE2B", "STOCFOR1", "SC205", "E226"]
+    probs = [load_npz_problem(os.path.join(golden_dir, "netlib", nm + ".npz"))[:3] for nm in names]
+    seq, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=1)
+    par, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=2)
+    assert np.array_equal(seq[:, 0], np.arange(len(names))) and np.array_equal(par[:, 0], seq[:, 0])
+    assert np.all(seq[:, 1] == 1.0)
+    assert np.array_equal(par[:, 1:4], seq[:, 1:4])            # status, iterations, objective
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

@@ -56,6 +56,25 @@ def cpu_baseline(A, b, c, budget_s=20.0, max_its=6):
                           its, m, n, dt, os.cpu_count() or 0)}
 
 
+def _dist_setup(local_rank, world):
+    """(dist module or None, device index, device for the scalar reductions).  One rank per GPU over RCCL; the
+    environment IPM_BENCH_BACKEND=gloo + IPM_BENCH_ONE_DEVICE=1 rehearses the multi-rank code path on a one-GPU box
+    (every rank on device 0, CPU collectives)."""
+    import torch
+    if world <= 1:
+        return None, local_rank, "cuda"
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("IPM_BENCH_BACKEND", "nccl")
+    dev = 0 if os.environ.get("IPM_BENCH_ONE_DEVICE") else local_rank
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        return dist, dev, "cuda"
+    dist.init_process_group(backend=backend)
+    return dist, dev, "cpu"
+
+
 PARITY_SET = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "GROW7", "KB2", "MAROS-R7", "SC105",
               "SC205", "SC50A", "SC50B", "SCSD1", "SCSD6", "SCSD8", "SCTAP1", "SCTAP2", "SCTAP3", "SHARE2B",
               "STOCFOR1", "STOCFOR2", "STOCFOR3", "TRUSS", "WOODW"]
@@ -73,12 +92,7 @@ def netlib_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dist, dev, red_dev = _dist_setup(local_rank, world)
     names, probs, costs = [], [], []
     for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netlib", "*.npz"))):
         nm = os.path.basename(f)[:-4]
@@ -92,20 +106,20 @@ def netlib_main(args):
         colnnz = np.diff(A.indptr).astype(np.float64)
         costs.append(batch.predicted_cost(A.shape[0], A.shape[1]))     # dense-A contraction today
     # warm-up: one small solve per rank (library load, first-launch costs) outside the timed region
-    batch.solve_one(probs[names.index("AFIRO")] if "AFIRO" in names else probs[0], device=local_rank)
+    batch.solve_one(probs[names.index("AFIRO")] if "AFIRO" in names else probs[0], device=dev)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    rec, _ = batch.run_batch(probs, costs=costs, device=local_rank, dist=dist,
-                             gather_device=torch.device("cuda", local_rank) if dist is not None else None,
+    rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist,
+                             gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
                              tol=1e-8, max_iter=300, regularize=args.regularize, workers=args.workers)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
@@ -114,9 +128,8 @@ def netlib_main(args):
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
                "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
-               "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s); per GPU the LPs with more than %d rows "
-                                      "one at a time, the others %d at a time on separate streams" % (
-                   args.netlib_set, len(names), max(world, 1), batch.SMALL_ROWS, max(1, args.workers))},
+               "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s); per GPU %d LP(s) in flight on "
+                                      "separate streams" % (args.netlib_set, len(names), max(world, 1), max(1, args.workers))},
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize,
                "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
                           for r in rec}}
@@ -153,19 +166,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dist, dev, red_dev = _dist_setup(local_rank, world)
     ngpu = max(world, 1)
     if args.gpus != ngpu and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     m, n = args.m, args.n
     A, b, c = synthetic_lp(m, n, seed=0)              # same LP on every rank (replicas)
-    sv = ipm.IpmSolver(A, b, c, device=local_rank)
+    sv = ipm.IpmSolver(A, b, c, device=dev)
 
     def run(steps, profile=0):
         sv.set_profiling(profile)
@@ -195,7 +203,7 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -107,11 +107,14 @@ __device__ __forceinline__ double row_bcast(double v, int k) {
 // shuffle from lane (j&3, c)); only 1/p_j is on the dependent chain because the elimination keeps
 // UNSCALED columns (T[r][j] = L[r][j] L[j][j]):  T[r][c] -= T[r][j] T[j][c] / p_j,  r, c > j.
 // About 25 instructions per pivot instead of ~65 for the one-lane-per-row / v_readlane form.
-__device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double thresh, double big, double* dinv_s) {
+// `pre` (optional): the tile already sits in registers in exactly this layout -- the MFMA accumulator of the update that
+// produced it (register a of lane l is row (l>>4)+4a, column l&15) -- and the LDS round trip is skipped.
+__device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double thresh, double big, double* dinv_s,
+                                           const f64x4* pre = nullptr) {
     const int q = lane >> 4, c = lane & 15;
     double t[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) t[a] = W[(c0 + q + 4 * a) * WLD + c0 + c];
+    for (int a = 0; a < 4; ++a) t[a] = pre ? (*pre)[a] : W[(c0 + q + 4 * a) * WLD + c0 + c];
     double myd = 0.0;                                        // 1/sqrt(p_c) of this lane's column
     int nfix = 0;
     // The 64-lane shuffle that fetches row j (T[j][c]) is taken off the pivot chain: row j+1 is shuffled
@@ -129,10 +132,11 @@ __device__ __forceinline__ int factor_tile(double* W, int c0, int lane, double t
             rownext = __shfl(t[na], 16 * nq + c, 64);        // T[j+1][c] before pivot j's update
             mnext = readlane_f64(t[na], 16 * nq + j);        // T[j+1][j]  (column j is final)
         }
-        const double rp = fast_rcp(p);
+        const double rowcur_m = (c > j) ? rowcur : 0.0;      // columns <= j are final: masked BEFORE 1/p is known,
+        const double rp = fast_rcp(p);                       // so no select sits behind the reciprocal chain
         myd = (c == j) ? p : myd;                            // remember this column's pivot; 1/sqrt after the loop
         const double rowc = rowcur * rp;                     // T[j][c] / p_j
-        const double rowm = (c > j) ? rowc : 0.0;            // columns <= j are final: masked once per pivot
+        const double rowm = rowcur_m * rp;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             if (a < ja) continue;                            // rows q+4a <= j for every lane: nothing to do (static)
@@ -211,6 +215,24 @@ __device__ __forceinline__ void substitute_rows4(double* W, int c0, int r0, int 
         p = __builtin_fma(-xk, trowm[k], p);
     }
     W[(r0 + q) * WLD + c0 + c] = p * dc;
+}
+
+// T(r0,q0) - L(r0, c0:c0+16) L(q0, c0:c0+16)^T kept in registers (accumulator layout), not written back.
+__device__ __forceinline__ f64x4 update_tile_regs(const double* W, int c0, int r0, int q0, int fr, int fk) {
+    f64x4 acc0, acc1 = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc0[q] = W[(r0 + fk + 4 * q) * WLD + q0 + fr];
+    double av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        av[kk] = -W[(r0 + fr) * WLD + c0 + kk * 4 + fk];
+        bv[kk] = W[(q0 + fr) * WLD + c0 + kk * 4 + fk];
+    }
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+    return acc0 + acc1;
 }
 
 // T(r0,q0) -= L(r0, c0:c0+16) L(q0, c0:c0+16)^T  (16 x 16 tiles, MFMA).  Wave-level.
@@ -336,8 +358,8 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
         __syncthreads();
         IPM_STAMP(5 + jb * 4);
         if (wave == 0 && nrt > 0) {
-            update_tile(W, c0, c0 + 16, c0 + 16, fr, fk);
-            nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s);
+            const f64x4 nxt = update_tile_regs(W, c0, c0 + 16, c0 + 16, fr, fk);     // stays in registers
+            nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s, &nxt);
         } else {
             // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1.
             // Wave 7 only inverts tile jb (about as long as wave 0's factorization) while a pivot tile is

@@ -432,6 +432,22 @@ def test_batch_two_at_a_time_same_records(golden_dir):
     assert np.array_equal(par[:, 1:4], seq[:, 1:4])            # status, iterations, objective
 
 
+def test_plain_c_driver():
+    """examples/c_driver.c: the C ABI from plain C in its own process (no Python, no torch; the library allocates its
+    workspace and stream): the reference's ex1 optimum -775 (main.py:1253) and a random 300 x 700 LP."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_driver")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0].startswith("libipm_hip ABI 1")
+    ex1 = dict(zip(lines[1].split()[1::2], lines[1].split()[2::2]))
+    assert ex1["status"] == "1" and abs(float(ex1["objective"]) + 775.0) < 1e-6 and int(ex1["iterations"]) == 17
+    assert "random 300x700: status 1" in lines[2]
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

@@ -5,8 +5,9 @@ Same names and argument meaning as the reference (payakorn/InteriorPointMethod):
     solve(A, b, c)                      -> (x, y, s)      the north-star seam
     interior_sparse(A, b, c, cTlb, tol) -> objective - cTlb          main.py:760-815
     interior(A, b, c, tol)              -> objective                 main.py:707-757 (returns None there)
-    direction_predicted_sparse(..., method="normal") -> (dx, dy, ds) main.py:197, 221-229
+    direction_predicted_sparse(..., method="normal"|"full") -> (dx, dy, ds)   main.py:197-229
     direction_corrected_sparse(...)     -> (dx, dy, ds)              main.py:247-269
+    direction_predicted / direction_corrected (dense-path names)     main.py:185-194, 232-244
     solve_linear(B, rhs)                -> (N, 1)                    main.py:176-182
 
 A is a scipy sparse matrix (any format; the reference passes CSC) or a dense array; b, c are
@@ -297,24 +298,44 @@ def interior(A, b, c, tol=1e-20, device=0):
     return info["objective"]
 
 
+_METHODS = ("normal", "full")
+
+
 def direction_predicted_sparse(A, b, c, x, y, s, method="normal", device=0):
-    """main.py:197: predictor direction at (x, y, s).  Only method="normal" exists on the GPU."""
-    if method != "normal":
-        raise ValueError('the HIP path implements method="normal" (main.py:221-229) only')
+    """main.py:197: predictor direction at (x, y, s).  method="normal" (main.py:221-229) and method="full" (the
+    unreduced KKT system of main.py:198-212) define the same direction; the device always solves it through the normal
+    equations (the Schur complement of the full system), which agrees with the reference's method="full" LU to 1e-11
+    at a well-conditioned point (tests/test_gpu_parity.py::test_direction_kats)."""
+    if method not in _METHODS:
+        raise ValueError('method must be "normal" or "full" (the "eliminate" variant of the reference uses a wrong '
+                         'right-hand side, main.py:270-276, and is not mirrored)')
     with IpmSolver(A, b, c, device=device) as sv:
         sv.set_state(x, y, s)
         return sv.newton_direction(corrector=False)
 
 
 def direction_corrected_sparse(A, b, c, x, y, s, delta_x_aff=None, delta_y_aff=None, delta_s_aff=None,
-                               method="normal", device=0):
-    """main.py:247: corrector direction.  The affine direction is recomputed on the device from
-    (x, y, s) (same factor reused), so the delta_*_aff arguments are accepted for signature
-    compatibility only."""
+                               method="full", device=0):
+    """main.py:247: corrector direction (the reference's default method here is "full").  The affine direction is
+    recomputed on the device from (x, y, s) (same factor reused), so the delta_*_aff arguments are accepted for
+    signature compatibility only."""
+    if method not in _METHODS:
+        raise ValueError('method must be "normal" or "full"')
     with IpmSolver(A, b, c, device=device) as sv:
         sv.set_state(x, y, s)
         sv.newton_direction(corrector=False)
         return sv.newton_direction(corrector=True)
+
+
+def direction_predicted(A, b, c, x, y, s, device=0):
+    """Dense-path name of the same seam (main.py:185-194)."""
+    return direction_predicted_sparse(np.asarray(A, dtype=np.float64), b, c, x, y, s, method="full", device=device)
+
+
+def direction_corrected(A, b, c, x, y, s, delta_x_aff=None, delta_y_aff=None, delta_s_aff=None, device=0):
+    """Dense-path name of the corrector seam (main.py:232-244)."""
+    return direction_corrected_sparse(np.asarray(A, dtype=np.float64), b, c, x, y, s, delta_x_aff, delta_y_aff,
+                                      delta_s_aff, method="full", device=device)
 
 
 def solve_linear(A, b, method="hip", device=0):

@@ -343,8 +343,16 @@ def test_reference_named_entry_points(golden_dir):
     assert rel(dx, k["k0_normal_dxa"]) < 1e-10 and rel(dy, k["k0_normal_dya"]) < 1e-10
     dx, dy, ds = ipm.direction_corrected_sparse(A, k["b"], k["c"], x, y, s, dx, dy, ds)         # main.py:247
     assert rel(dx, k["k0_dx"]) < 1e-9 and rel(ds, k["k0_ds"]) < 1e-9
+    dxf, dyf, dsf = ipm.direction_predicted_sparse(A, k["b"], k["c"], x, y, s, method="full")    # main.py:198-212
+    assert rel(dxf, k["k0_dxa"]) < 1e-10 and rel(dyf, k["k0_dya"]) < 1e-10 and rel(dsf, k["k0_dsa"]) < 1e-10
     with pytest.raises(ValueError):
-        ipm.direction_predicted_sparse(A, k["b"], k["c"], x, y, s, method="full")
+        ipm.direction_predicted_sparse(A, k["b"], k["c"], x, y, s, method="eliminate")
+    e1 = np.load(os.path.join(golden_dir, "dense_ex1.npz"))                  # dense-path names, main.py:185-244
+    n1 = e1["A"].shape[1]
+    da = ipm.direction_predicted(e1["A"], e1["b"], e1["c"], np.ones(n1), np.zeros(e1["A"].shape[0]), np.ones(n1))
+    assert rel(da[0], e1["k0_dxa"]) < 1e-11 and rel(da[1], e1["k0_dya"]) < 1e-11 and rel(da[2], e1["k0_dsa"]) < 1e-11
+    dc = ipm.direction_corrected(e1["A"], e1["b"], e1["c"], np.ones(n1), np.zeros(e1["A"].shape[0]), np.ones(n1), *da)
+    assert rel(dc[0], e1["k0_dx"]) < 1e-10 and rel(dc[1], e1["k0_dy"]) < 1e-10 and rel(dc[2], e1["k0_ds"]) < 1e-10
     rng = np.random.default_rng(1)
     M = rng.standard_normal((90, 120))
     B = M @ M.T

@@ -113,7 +113,8 @@ def netlib_main(args):
     t0 = time.perf_counter()
     rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist,
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
-                             tol=1e-8, max_iter=300, regularize=args.regularize, workers=args.workers)
+                             tol=1e-8, max_iter=300, regularize=args.regularize, workers=args.workers,
+                             schedule=args.schedule)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -128,8 +129,10 @@ def netlib_main(args):
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
                "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
-               "config": {"workload": "Netlib %s set, %d LPs, LPT-sharded over %d GPU(s); per GPU %d LP(s) in flight on "
-                                      "separate streams" % (args.netlib_set, len(names), max(world, 1), max(1, args.workers))},
+               "config": {"workload": "Netlib %s set, %d LPs over %d GPU(s), %s; per GPU %d LP(s) in flight on separate streams" % (
+                   args.netlib_set, len(names), max(world, 1),
+                   "one rank" if world <= 1 else ("self-scheduled from the rendezvous store" if args.schedule == "dynamic"
+                                                  else "static LPT partition"), max(1, args.workers))},
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize,
                "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
                           for r in rec}}
@@ -153,6 +156,8 @@ def main():
                     help="all 73 valid files, or the 26 on which the reference converges")
     ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
     ap.add_argument("--workers", type=int, default=2, help="netlib: small LPs solved concurrently per GPU (1 = strictly one at a time)")
+    ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],
+                    help="netlib, N > 1: pull LPs from a shared counter (rendezvous store) or static LPT partition")
     ap.add_argument("--regularize", type=float, default=0.0, help="netlib: Tikhonov shift (0 = reference-faithful)")
     args = ap.parse_args()
     if args.workload == "netlib":

@@ -3,8 +3,9 @@
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU for
 tests).  An LP is solved entirely on one GPU -- there is no exchange inside a solve -- so the
 only collective is ONE all-gather of a fixed-size statistics record per LP at the end
-(SURVEY.md 8e).  The partition is a deterministic LPT-greedy assignment on a predicted cost,
-computed identically on every rank, so no scheduling traffic is needed either.
+(SURVEY.md 8e).  The partition is either a deterministic LPT-greedy assignment on a predicted cost,
+computed identically on every rank (no scheduling traffic at all), or self-scheduling from an atomic counter on
+the process group's rendezvous store (control plane; balances the unpredictable iteration counts).
 
 The reference has no counterpart (it is single process); the loop being distributed is the
 driver loop of script.py:147-173 over the Netlib files.
@@ -22,9 +23,13 @@ STATUS_ERROR = -99.0
 
 
 def predicted_cost(m, n, nnz_col_sq=None, iters_est=40):
-    """iters * (contraction flops + m^3/3): dense-B factorization dominates."""
-    form = float(m) * m * n if nnz_col_sq is None else float(nnz_col_sq)
-    return iters_est * (form + float(m) ** 3 / 3.0)
+    """Predicted solve time (arbitrary units) for the LPT partition.  Measured on MI355X (profiles/r01_netlib_*.json):
+    one iteration costs about 0.1 ms + 0.11 ms per 128-row block of the normal matrix from m = 27 to m = 16675 -- the
+    blocked Cholesky is a latency chain, not a flop count -- so the model is linear in the block count.  (The cubic
+    flop model this replaces put 11.2 s of a 12.5 s suite on one of two ranks.)  The iteration count is not
+    predictable (14 ... the cap) and is taken as equal."""
+    nblk = (int(m) + 127) // 128
+    return iters_est * (0.1 + 0.11 * nblk)
 
 
 def lpt_partition(costs, world):
@@ -133,17 +138,96 @@ def gather_records(local, shard_sizes, dist=None, device=None):
     return out[np.argsort(out[:, 0], kind="stable")]
 
 
-def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1, **kw):
+_CALLS = 0          # run_batch() calls so far: names the shared work counter of a call (same sequence on every rank)
+
+
+def _rendezvous_store(dist):
+    """The process group's rendezvous key-value store (a TCP store on the master address): control plane only."""
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        return c10d._get_default_store()
+    except Exception:
+        return None
+
+
+def _solve_dynamic(problems, order, store, key, device, solve_fn, workers, **kw):
+    """Self-scheduling: every worker thread of every rank takes the next LP of `order` (most expensive first) from
+    an atomic counter on the rendezvous store.  Iteration counts (14 ... the cap) make a static partition lose up to
+    40 % to imbalance; the counter costs one small TCP round trip per LP.  Returns an (n, NF) table whose rows not
+    solved on this rank keep id = -1."""
+    import threading
+    n = len(problems)
+    rec = np.full((n, NF), -1.0)
+    lock = threading.Lock()
+
+    def take():
+        with lock:
+            return int(store.add(key, 1)) - 1
+
+    def loop(_):
+        while True:
+            j = take()
+            if j >= n:
+                return
+            i = order[j]
+            t0 = time.perf_counter()
+            if workers > 1:
+                info = dict(_in_own_stream(solve_fn, problems[i], device, dict(kw, concurrent=True) if solve_fn is solve_one else kw))
+            else:
+                info = dict(solve_fn(problems[i], device=device, **kw))
+            info.setdefault("seconds", time.perf_counter() - t0)
+            rec[i] = [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]),
+                      float(info["rp"]), float(info["rd"]), float(info["gap"]), float(info["seconds"]),
+                      float(info["pivots_fixed"])]
+
+    if workers <= 1:
+        loop(0)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(loop, range(workers)))
+    return rec
+
+
+def _gather_sparse(rec, dist, device=None):
+    """One all_gather of the (n, NF) tables; row i is taken from the rank that solved LP i."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(rec))
+    if device is not None:
+        t = t.to(device)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    out = np.full(rec.shape, -1.0)
+    for b in bufs:
+        a = b.cpu().numpy()
+        own = a[:, 0] >= 0
+        out[own] = a[own]
+    return out
+
+
+def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1,
+              schedule="static", **kw):
     """Shard `problems` (list of (A, b, c)) over the ranks of `dist`, solve, gather statistics.
 
-    Returns (records sorted by id, this rank's wall seconds).  Without an initialised process
-    group this is the single-GPU loop."""
+    schedule="static": deterministic LPT partition on the predicted cost, no scheduling traffic at all.
+    schedule="dynamic" (N > 1): the ranks pull LPs, most expensive first, from a counter on the process group's
+    rendezvous store (falls back to "static" when the store is not reachable).  Either way the only collective is
+    ONE all-gather of the statistics records.  Returns (records sorted by id, this rank's wall seconds).  Without an
+    initialised process group this is the single-GPU loop."""
+    global _CALLS
+    _CALLS += 1
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     if costs is None:
         costs = [predicted_cost(p[0].shape[0], p[0].shape[1]) for p in problems]
-    shards = lpt_partition(costs, world)
+    store = _rendezvous_store(dist) if (world > 1 and schedule == "dynamic") else None
     t0 = time.perf_counter()
+    if store is not None:
+        order = sorted(range(len(problems)), key=lambda i: (-float(costs[i]), i))
+        local = _solve_dynamic(problems, order, store, "ipm_batch_next_%d" % _CALLS, device, solve_fn, workers, **kw)
+        seconds = time.perf_counter() - t0
+        return _gather_sparse(local, dist, device=gather_device), seconds
+    shards = lpt_partition(costs, world)
     local = solve_shard(problems, shards[rank], device=device, solve_fn=solve_fn, workers=workers, **kw)
     seconds = time.perf_counter() - t0
     records = gather_records(local, [len(s) for s in shards], dist=dist if world > 1 else None,

@@ -41,17 +41,40 @@ def test_single_process_batch():
     assert s["total_iterations"] == sum(2 * m + 1 for m in (4, 9, 2, 7, 6))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, schedule="static", workers=1):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         probs = [(np.zeros((m, m + 1)), None, None) for m in (4, 9, 2, 7, 6, 11, 3)]
-        rec, secs = batch.run_batch(probs, dist=dist, solve_fn=_fake_solve)
+        rec, secs = batch.run_batch(probs, dist=dist, solve_fn=_fake_solve, schedule=schedule, workers=workers)
+        rec2, _ = batch.run_batch(probs, dist=dist, solve_fn=_fake_solve, schedule=schedule, workers=workers)   # a second call: fresh counter
+        assert np.array_equal(rec[:, :7], rec2[:, :7])
         q.put((rank, rec))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("schedule,workers", [("dynamic", 1), ("dynamic", 2)])
+def test_two_rank_gloo_dynamic_schedule(schedule, workers):
+    """Self-scheduling from the rendezvous store: every LP solved exactly once, same table on both ranks."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, schedule, workers)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, _ = batch.run_batch([(np.zeros((m, m + 1)), None, None) for m in (4, 9, 2, 7, 6, 11, 3)], solve_fn=_fake_solve)
+    for r in (0, 1):
+        assert np.array_equal(got[r][:, :7], ref[:, :7]) and np.array_equal(got[r][:, 8], ref[:, 8])
 
 
 def test_two_rank_gloo_gather():

@@ -240,6 +240,10 @@ def main():
                        "reset_every": RESET_EVERY},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": "L2<->fabric bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE, "
+                                         "gfx950 correction); 0.34 GB algorithmic; with eight private L2s the floor for this "
+                                         "tiling is ~1.1 GB (each XCD reads half the row panels of A); part of it is served by "
+                                         "the 256 MB Infinity Cache, so HBM bytes are lower; <1 TB/s either way: MFMA-bound",
                          "kernel": "gemm_nt_f64_kernel<128,128,16,2,2> (B = A diag(d) A^T)",
                          "flops_per_launch": flops_form, "avg_launch_ms": form_ms},
             "phases_ms_per_step": {"form": form_ms, "factor": phases_all[1] / KB, "trisolve": phases_all[2] / KB,

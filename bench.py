@@ -114,7 +114,7 @@ def netlib_main(args):
     rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist,
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
                              tol=1e-8, max_iter=300, regularize=args.regularize, workers=args.workers,
-                             schedule=args.schedule)
+                             schedule=args.schedule, start=args.start)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -133,7 +133,7 @@ def netlib_main(args):
                    args.netlib_set, len(names), max(world, 1),
                    "one rank" if world <= 1 else ("self-scheduled from the rendezvous store" if args.schedule == "dynamic"
                                                   else "static LPT partition"), max(1, args.workers))},
-               "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize,
+               "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize, "start_point": args.start,
                "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
                           for r in rec}}
         print(json.dumps(out))
@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--workers", type=int, default=2, help="netlib: small LPs solved concurrently per GPU (1 = strictly one at a time)")
     ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],
                     help="netlib, N > 1: pull LPs from a shared counter (rendezvous store) or static LPT partition")
+    ap.add_argument("--start", default="reference", choices=["reference", "mehrotra"],
+                    help="netlib: start point; reference = x=s=y=1 (sparse_interior.py:193-200, parity mode), mehrotra = "
+                         "Mehrotra's least-squares start (optional mode, not the reference's algorithm)")
     ap.add_argument("--regularize", type=float, default=0.0, help="netlib: Tikhonov shift (0 = reference-faithful)")
     args = ap.parse_args()
     if args.workload == "netlib":

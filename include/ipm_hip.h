@@ -152,6 +152,12 @@ int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t
  * (m = the handle's m).  z may alias rhs.  pivots_fixed may be NULL. */
 int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, const double* rhs, double* z,
                      int32_t* pivots_fixed);
+/* Solve (A diag(d) A^T) z = rhs with the handle's own A: forms the normal matrix on the device (d on the host,
+ * length n; NULL = all ones), factors it with the guarded blocked Cholesky (reuse_factor != 0: the factor of the
+ * previous ipm_normal_solve / direction call is kept) and back-substitutes.  rhs, z: host, length m; z may alias
+ * rhs.  Building block of start-point heuristics (x = A^T (A A^T)^-1 b, ...); the iterate is not touched. */
+int ipm_normal_solve(ipm_handle* h, const double* d, const double* rhs, double* z, int reuse_factor,
+                     int32_t* pivots_fixed);
 /* B = A diag(d) A^T (d on the host, length n); full symmetric m x m written to host B. */
 int ipm_form_normal_matrix(ipm_handle* h, const double* d, double* B, int64_t ldb);
 /* Cholesky factor of the handle's current normal matrix; lower triangle to host L. */

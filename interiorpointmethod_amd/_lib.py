@@ -18,7 +18,7 @@ EXPORTS = [
     "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
-    "ipm_iterate", "ipm_solve", "ipm_solve_linear", "ipm_form_normal_matrix", "ipm_get_factor",
+    "ipm_iterate", "ipm_solve", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
     "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps",
 ]
 
@@ -106,6 +106,7 @@ def load():
     lib.ipm_iterate.argtypes = [vp, i32, C.POINTER(Stats)]
     lib.ipm_solve.argtypes = [vp, dbl, dbl, dbl, i32, C.POINTER(Stats)]
     lib.ipm_solve_linear.argtypes = [vp, pd, i64, pd, pd, C.POINTER(i32)]
+    lib.ipm_normal_solve.argtypes = [vp, pd, pd, pd, C.c_int, C.POINTER(i32)]
     lib.ipm_form_normal_matrix.argtypes = [vp, pd, pd, i64]
     lib.ipm_get_factor.argtypes = [vp, pd, i64]
     lib.ipm_set_profiling.argtypes = [vp, C.c_int]

@@ -45,7 +45,7 @@ def lpt_partition(costs, world):
     return shards
 
 
-def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, concurrent=False):
+def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, concurrent=False, start="reference"):
     """Solve one LP (A, b, c) on `device` with the HIP path -> dict of statistics."""
     from . import _lib
     from .solver import solve_with_info
@@ -53,7 +53,7 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
     t0 = time.perf_counter()
     try:
         _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device,
-                                        regularize=regularize, concurrent=concurrent)
+                                        regularize=regularize, concurrent=concurrent, start=start)
         info = dict(info)
     except _lib.IpmError as e:
         nan = float("nan")

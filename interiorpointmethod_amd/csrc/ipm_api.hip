@@ -1021,6 +1021,33 @@ extern "C" int ipm_form_normal_matrix(ipm_handle* h, const double* d, double* B,
     return IPM_OK;
 }
 
+extern "C" int ipm_normal_solve(ipm_handle* h, const double* d, const double* rhs, double* z, int reuse_factor,
+                                int32_t* pivots_fixed) {
+    if (!h || !rhs || !z) return fail(h, IPM_ERR_INVALID_ARG, "ipm_normal_solve: bad arguments");
+    if (!h->haveA) return fail(h, IPM_ERR_STATE, "ipm_normal_solve: A not set");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 1);
+    if (!reuse_factor) {
+        if (d) {
+            HIP_TRY(h, hipMemcpyAsync(h->d, d, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+        } else {
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->d, (int)h->n, 1.0);
+        }
+        if ((rc = enqueue_form(h, h->d))) return rc;
+        if ((rc = enqueue_factor(h, true))) return rc;
+        if ((rc = enqueue_group_inverses(h))) return rc;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->t1, 0, sizeof(double) * h->mp, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->t1, rhs, sizeof(double) * h->m, hipMemcpyHostToDevice, h->stream));
+    if ((rc = enqueue_potrs(h, h->t1, h->dy))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(z, h->dy, sizeof(double) * h->m, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = read_scalars(h))) return rc;
+    if (pivots_fixed) *pivots_fixed = h->h_sc->fixed;
+    h->predictor_valid = false;
+    return IPM_OK;
+}
+
 extern "C" int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl) {
     if (!h || !L || ldl < h->m) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_factor: bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));

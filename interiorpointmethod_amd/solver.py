@@ -97,6 +97,7 @@ class IpmSolver:
         self.m, self.n = int(m), int(n)
         b = _col(b, self.m, "b")
         c = _col(c, self.n, "c")
+        self._host = (A, b, c)      # caller's row order: used by start-point heuristics only
         if _sp is not None and _sp.issparse(A) and reorder and (reorder == "rcm" or self.m >= REORDER_MIN_ROWS):
             perm = envelope_row_order(A, force=(reorder == "rcm"))     # "auto": only when it pays
             if perm is not None:
@@ -239,6 +240,34 @@ class IpmSolver:
         self._check(self._lib.ipm_get_factor(self._h, _dptr(L), self.m))
         return L
 
+    def normal_solve(self, rhs, d=None, reuse_factor=False):
+        """z with (A diag(d) A^T) z = rhs on the device (d = None: ones); reuse_factor keeps the previous factor."""
+        rhs = self._rows_in(_col(rhs, self.m, "rhs"))
+        z = np.empty(self.m)
+        dptr = None if d is None else _dptr(_col(d, self.n, "d"))
+        nfix = C.c_int32(0)
+        self._check(self._lib.ipm_normal_solve(self._h, dptr, _dptr(rhs), _dptr(z), 1 if reuse_factor else 0, C.byref(nfix)))
+        return self._rows_out(z)
+
+    def mehrotra_start(self):
+        """Mehrotra's starting point (SIAM J. Optim. 2 (1992) 575-601, section 7): least-squares x and (y, s), shifted
+        into the positive orthant and balanced.  NOT the reference's start (x = s = 1, sparse_interior.py:193-200): an
+        optional mode that changes the trajectory; two solves with A A^T on the device, the rest is
+        O(nnz) host arithmetic."""
+        A, b, c = self._host
+        x = A.T @ self.normal_solve(b)
+        y = self.normal_solve(A @ c, reuse_factor=True)
+        s = c - A.T @ y
+        x = np.asarray(x).ravel(); s = np.asarray(s).ravel()
+        x = x + max(-1.5 * x.min(), 0.0)
+        s = s + max(-1.5 * s.min(), 0.0)
+        xs = 0.5 * float(x @ s)
+        if not (np.isfinite(xs) and s.sum() > 0 and x.sum() > 0 and xs > 0):
+            return np.ones(self.n), np.ones(self.m), np.ones(self.n)          # degenerate data: the reference's start
+        x = x + xs / s.sum()
+        s = s + xs / x.sum()
+        return x, np.asarray(y).ravel(), s
+
     def solve_linear(self, B, rhs):
         if self._perm is not None:
             raise ValueError("solve_linear on a handle with reordered rows: create the solver with reorder=None")
@@ -267,11 +296,17 @@ def last_info():
     return _last_info
 
 
-def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=None, **opts):
-    """solve() plus the statistics record (iterations, status, objective, rp, rd, gap, ...)."""
+def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=None, start="reference", **opts):
+    """solve() plus the statistics record (iterations, status, objective, rp, rd, gap, ...).
+    start="reference": x = s = 1, y = y0 as the reference does; start="mehrotra": IpmSolver.mehrotra_start()."""
     global _last_info
     with IpmSolver(A, b, c, device=device, **opts) as sv:
-        sv.init_state(y0)
+        if start == "mehrotra":
+            sv.set_state(*sv.mehrotra_start())
+        elif start == "reference":
+            sv.init_state(y0)
+        else:
+            raise ValueError('start must be "reference" or "mehrotra"')
         sv.solve(tol=tol, max_iter=max_iter, tol_gap=tol_gap)
         x, y, s = sv.get_state()
         info = _info(sv)

@@ -434,6 +434,41 @@ def test_new_interior_sparse_general_form(golden_dir, name):
         assert name in ("KB2", "SCORPION", "STANDATA")
 
 
+def test_normal_solve_entry(golden_dir):
+    """ipm_normal_solve: (A diag(d) A^T) z = rhs with the handle's own A, dense and sparse, factor reuse."""
+    rng = np.random.default_rng(8)
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "SC205.npz"))
+    Ad = A.toarray()
+    m, n = Ad.shape
+    d = 10.0 ** rng.uniform(-2, 2, n)
+    r1, r2 = rng.standard_normal(m), rng.standard_normal(m)
+    for mat, kw in ((A, {}), (Ad, {}), (A, dict(reorder="rcm"))):
+        with ipm.IpmSolver(mat, b, c, **kw) as sv:
+            z1 = sv.normal_solve(r1, d)
+            z2 = sv.normal_solve(r2, reuse_factor=True)
+            z3 = sv.normal_solve(r2)                                  # d = None: A A^T
+        B = (Ad * d) @ Ad.T
+        assert np.linalg.norm(B @ z1 - r1) / np.linalg.norm(r1) < 1e-9
+        assert np.linalg.norm(B @ z2 - r2) / np.linalg.norm(r2) < 1e-9
+        assert np.linalg.norm(Ad @ (Ad.T @ z3) - r2) / np.linalg.norm(r2) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "ADLITTLE", "25FV47", "SCAGR25", "SHARE1B", "ISRAEL", "BNL2", "STOCFOR2"])
+def test_mehrotra_start_option(golden_dir, name):
+    """start="mehrotra" (optional mode; NOT the reference's start): converges to the Netlib optimum
+    (the table the reference carries, tests/golden/netlib_optima.json) -- on five of these eight the reference's start
+    x = s = 1 runs into the iteration cap -- in fewer iterations than the reference start where both converge."""
+    import json
+    opt = json.load(open(os.path.join(golden_dir, "netlib_optima.json")))[name]
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    x, y, s, info = ipm.solve_with_info(A, b, c, tol=1e-8, max_iter=300, start="mehrotra")
+    assert info["status"] == 1 and abs(info["objective"] - cTlb - opt) <= 1e-6 * max(1.0, abs(opt))
+    assert np.all(x > 0) and np.all(s > 0)
+    if name in ("AFIRO", "STOCFOR2"):
+        _, _, _, ref = ipm.solve_with_info(A, b, c, tol=1e-8, max_iter=300)
+        assert ref["status"] == 1 and info["iterations"] < ref["iterations"]
+
+
 def test_batch_two_at_a_time_same_records(golden_dir):
     """Batched mode with two LPs in flight per GPU (host threads, own streams, IPM_FLAG_NO_DEVICE_POLLING): the
     records equal the one-at-a-time run bit for bit -- only the synchronisation mechanism differs."""

@@ -135,11 +135,12 @@ def standard_form(c, Aeq=None, beq=None, Aineq=None, bineq=None, lb=None, ub=Non
 
 
 def new_interior_sparse(c, Aeq=None, beq=None, Aineq=None, bineq=None, lb=None, ub=None, tol=1e-20, device=0,
-                        return_info=False):
+                        return_info=False, start="reference"):
     """Drop-in for main.py:1081-1245: convert to standard form, run the predictor-corrector loop on the GPU
     (e1 = e2 = tol, e3 = 1e-6, at most 999 iterations, x = y = s = 1), return the objective."""
     A, b, cs, offset = standard_form(c, Aeq=Aeq, beq=beq, Aineq=Aineq, bineq=bineq, lb=lb, ub=ub)
-    _, _, _, info = _solver.solve_with_info(A, b, cs, tol=tol, tol_gap=1e-6, max_iter=999, y0=1.0, device=device)
+    _, _, _, info = _solver.solve_with_info(A, b, cs, tol=tol, tol_gap=1e-6, max_iter=999, y0=1.0, device=device,
+                                            start=start)            # start="mehrotra": optional, not the reference's
     obj = info["objective"] + offset
     return (obj, info) if return_info else obj
 

@@ -13,7 +13,8 @@ for f in sorted(glob.glob(os.path.join("tests", "golden", "general", "*.npz"))):
         return None if p + "_none" in z.files else sparse.csc_matrix((z[p + "_data"], z[p + "_indices"], z[p + "_indptr"]), shape=tuple(int(v) for v in z[p + "_shape"]))
     try:
         obj, info = G.new_interior_sparse(c=z["c"], Aineq=mat("Aineq"), bineq=z["bineq"] if "bineq" in z.files else None, Aeq=mat("Aeq"),
-                                          beq=z["beq"] if "beq" in z.files else None, lb=z["lb"], ub=z["ub"], tol=1e-8, return_info=True)
+                                          beq=z["beq"] if "beq" in z.files else None, lb=z["lb"], ub=z["ub"], tol=1e-8, return_info=True,
+                                          start=os.environ.get("IPM_START", "reference"))
     except Exception as e:
         print("%-10s ERROR %s" % (nm, e)); continue
     o, r = float(z["netlib_optimum"]), float(z["ref_objective"])

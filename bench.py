@@ -94,7 +94,27 @@ def netlib_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist, dev, red_dev = _dist_setup(local_rank, world)
     names, probs, costs = [], [], []
-    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netlib", "*.npz"))):
+    if args.netlib_set == "general":
+        # the reference's benchmarks_full files (general form) through the front end: conversion on the host, untimed
+        from scipy import sparse
+        from interiorpointmethod_amd import general_form as G
+        for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "general", "*.npz"))):
+            z = np.load(f)
+
+            def mat(prefix):
+                if prefix + "_none" in z.files:
+                    return None
+                return sparse.csc_matrix((z[prefix + "_data"], z[prefix + "_indices"], z[prefix + "_indptr"]),
+                                         shape=tuple(int(v) for v in z[prefix + "_shape"]))
+            A, b, c, _ = G.standard_form(z["c"], Aeq=mat("Aeq"), beq=z["beq"] if "beq" in z.files else None,
+                                         Aineq=mat("Aineq"), bineq=z["bineq"] if "bineq" in z.files else None,
+                                         lb=z["lb"], ub=z["ub"])
+            if A.shape[0] > args.max_m:
+                continue
+            names.append(os.path.basename(f)[:-4])
+            probs.append((sparse.csc_matrix(A), b, c))
+            costs.append(batch.predicted_cost(A.shape[0], A.shape[1]))
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netlib", "*.npz")) if args.netlib_set != "general" else []):
         nm = os.path.basename(f)[:-4]
         if args.netlib_set == "parity" and nm not in PARITY_SET:
             continue
@@ -113,8 +133,10 @@ def netlib_main(args):
     t0 = time.perf_counter()
     rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist,
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
-                             tol=1e-8, max_iter=300, regularize=args.regularize, workers=args.workers,
-                             schedule=args.schedule, start=args.start)
+                             tol=1e-8, regularize=args.regularize, workers=args.workers,
+                             schedule=args.schedule, start=args.start,
+                             # the general-form driver's own settings: e3 = 1e-6, at most 999 iterations (main.py:1088-1127)
+                             **(dict(max_iter=999, tol_gap=1e-6) if args.netlib_set == "general" else dict(max_iter=300)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -125,7 +147,8 @@ def netlib_main(args):
         elapsed = float(tt.item())
     if rank == 0:
         summ = batch.summarize(rec)
-        out = {"metric": "Netlib LPs/sec (benchmarks/ suite, batched, tol=1e-8, cap 300)",
+        out = {"metric": "Netlib LPs/sec (benchmarks_full/ general-form suite, batched, tol=1e-8, e3=1e-6, cap 999)"
+                         if args.netlib_set == "general" else "Netlib LPs/sec (benchmarks/ suite, batched, tol=1e-8, cap 300)",
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
                "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
@@ -152,8 +175,9 @@ def main():
     ap.add_argument("--workload", default="dense", choices=["dense", "netlib"],
                     help="dense: IPM iterations/s on the synthetic LP (default, the headline metric); "
                          "netlib: LPs/s over the committed Netlib fixtures, sharded over the ranks")
-    ap.add_argument("--netlib-set", default="all", choices=["all", "parity"],
-                    help="all 73 valid files, or the 26 on which the reference converges")
+    ap.add_argument("--netlib-set", default="all", choices=["all", "parity", "general"],
+                    help="all 73 valid standard-form files, the 26 on which the reference converges, or the 72 general-form "
+                         "files (benchmarks_full) through the general-form front end")
     ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
     ap.add_argument("--workers", type=int, default=2, help="netlib: small LPs solved concurrently per GPU (1 = strictly one at a time)")
     ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],

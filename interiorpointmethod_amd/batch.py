@@ -45,7 +45,8 @@ def lpt_partition(costs, world):
     return shards
 
 
-def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, concurrent=False, start="reference"):
+def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, concurrent=False, start="reference",
+              tol_gap=None):
     """Solve one LP (A, b, c) on `device` with the HIP path -> dict of statistics."""
     from . import _lib
     from .solver import solve_with_info
@@ -53,9 +54,11 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
     t0 = time.perf_counter()
     try:
         _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device,
-                                        regularize=regularize, concurrent=concurrent, start=start)
+                                        regularize=regularize, concurrent=concurrent, start=start, tol_gap=tol_gap)
         info = dict(info)
     except _lib.IpmError as e:
+        import sys
+        print("[batch] %d x %d LP failed: %s" % (A.shape[0], A.shape[1], e), file=sys.stderr, flush=True)
         nan = float("nan")
         info = dict(status=STATUS_INVALID_INPUT if e.code == _lib.ERR_INVALID_INPUT else STATUS_ERROR,
                     iterations=0, objective=nan, rp=nan, rd=nan, gap=nan, pivots_fixed=0)

@@ -470,16 +470,19 @@ def test_mehrotra_start_option(golden_dir, name):
 
 
 def test_general_form_all_fixtures_with_mehrotra_start(golden_dir):
-    """All 39 general-form fixtures (every benchmarks_full file with <= 1200 variables: inequality and equality rows,
+    """The 40 general-form fixtures with <= 1200 variables (benchmarks_full: inequality and equality rows,
     nonzero lower and finite upper bounds) through the front end with the optional Mehrotra start: every one converges
     to the Netlib optimum the reference lists (gap tolerance of this driver is 1e-6, so 1e-5 relative here).  The
     reference's own driver reaches the optimum on 13 of them."""
     import glob
     from interiorpointmethod_amd import general_form as G
     files = sorted(glob.glob(os.path.join(golden_dir, "general", "*.npz")))
-    assert len(files) >= 39
+    done = 0
     for f in files:
         z = np.load(f)
+        if z["c"].shape[0] > 1200:          # the larger files: tools/general_report.py / bench.py --netlib-set general
+            continue
+        done += 1
 
         def mat(prefix):
             if prefix + "_none" in z.files:
@@ -492,6 +495,7 @@ def test_general_form_all_fixtures_with_mehrotra_start(golden_dir):
         opt = float(z["netlib_optimum"])
         assert info["status"] == 1, (os.path.basename(f), info["status_name"])
         assert abs(obj - opt) <= 1e-5 * max(1.0, abs(opt)), (os.path.basename(f), obj, opt)
+    assert done >= 40
 
 
 def test_batch_two_at_a_time_same_records(golden_dir):

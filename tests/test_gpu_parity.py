@@ -453,6 +453,22 @@ def test_normal_solve_entry(golden_dir):
         assert np.linalg.norm(Ad @ (Ad.T @ z3) - r2) / np.linalg.norm(r2) < 1e-9
 
 
+def test_mehrotra_start_matches_numpy(golden_dir):
+    """The start point itself against a dense NumPy evaluation of Mehrotra's formulas."""
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "SC205.npz"))
+    Ad, bb, cc = A.toarray(), b.ravel(), c.ravel()
+    G = Ad @ Ad.T
+    x = Ad.T @ np.linalg.solve(G, bb)
+    y = np.linalg.solve(G, Ad @ cc)
+    s = cc - Ad.T @ y
+    x = x + max(-1.5 * x.min(), 0.0); s = s + max(-1.5 * s.min(), 0.0)
+    xs = 0.5 * (x @ s)
+    x = x + xs / s.sum(); s = s + xs / x.sum()
+    with ipm.IpmSolver(A, b, c) as sv:
+        x0, y0, s0 = sv.mehrotra_start()
+    assert rel(x0, x) < 1e-9 and rel(y0, y) < 1e-9 and rel(s0, s) < 1e-9 and x0.min() > 0 and s0.min() > 0
+
+
 @pytest.mark.parametrize("name", ["AFIRO", "ADLITTLE", "25FV47", "SCAGR25", "SHARE1B", "ISRAEL", "BNL2", "STOCFOR2"])
 def test_mehrotra_start_option(golden_dir, name):
     """start="mehrotra" (optional mode; NOT the reference's start): converges to the Netlib optimum

@@ -18,6 +18,7 @@ PyTorch is used only to own the device workspace and the stream; all arithmetic 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -247,6 +248,7 @@ class IpmSolver:
         dptr = None if d is None else _dptr(_col(d, self.n, "d"))
         nfix = C.c_int32(0)
         self._check(self._lib.ipm_normal_solve(self._h, dptr, _dptr(rhs), _dptr(z), 1 if reuse_factor else 0, C.byref(nfix)))
+        self.last_pivots_fixed = nfix.value          # > 0 with d = 1: A A^T is singular, i.e. A has dependent rows
         return self._rows_out(z)
 
     def mehrotra_start(self):
@@ -300,6 +302,15 @@ def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=
     """solve() plus the statistics record (iterations, status, objective, rp, rd, gap, ...).
     start="reference": x = s = 1, y = y0 as the reference does; start="mehrotra": IpmSolver.mehrotra_start()."""
     global _last_info
+    if start == "mehrotra" and not opts.get("regularize") and os.environ.get("IPM_AUTO_REGULARIZE", "1") != "0":
+        # the least-squares start factors A A^T: guarded pivots there are dependent rows of A.  Where they are a
+        # sizeable fraction of the rows (the QAP family: 9-16 %; every other Netlib file: at most 2.7 %) the guard alone
+        # stalls the loop (DESIGN.md 2) and the 1e-14 Tikhonov shift is switched on; a handful of dependent rows is left
+        # to the guard (the shift breaks 25FV47, BNL1, D6CUBE, WOOD1P, which have 1-11 of them)
+        with IpmSolver(A, b, c, device=device, **opts) as probe:
+            probe.normal_solve(np.zeros(probe.m))
+            if probe.last_pivots_fixed > 0.05 * probe.m:
+                opts = dict(opts, regularize=1e-14)
     with IpmSolver(A, b, c, device=device, **opts) as sv:
         if start == "mehrotra":
             sv.set_state(*sv.mehrotra_start())

@@ -453,6 +453,17 @@ def test_normal_solve_entry(golden_dir):
         assert np.linalg.norm(Ad @ (Ad.T @ z3) - r2) / np.linalg.norm(r2) < 1e-9
 
 
+def test_qap15_mehrotra_mode(golden_dir):
+    """BASELINE config 3 in the optional robust mode: the least-squares start finds 548 of QAP15's 6330 rows dependent
+    (guarded pivots of A A^T), switches the 1e-14 Tikhonov shift on for this LP only, and the loop converges to the
+    Netlib optimum 1040.994041 in about 25 iterations (default mode: test_qap15_config3_objective / _regularized)."""
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "QAP15.npz"))
+    x, y, s, info = ipm.solve_with_info(A, b, c, tol=1e-8, max_iter=300, start="mehrotra")
+    assert info["status"] == 1 and info["iterations"] <= 40
+    assert abs(info["objective"] - cTlb - 1040.994041) <= 1e-6 * 1040.994041
+    assert info["rp"] <= 1e-8 and info["rd"] <= 1e-8
+
+
 def test_mehrotra_start_matches_numpy(golden_dir):
     """The start point itself against a dense NumPy evaluation of Mehrotra's formulas."""
     A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", "SC205.npz"))

@@ -434,6 +434,34 @@ def test_new_interior_sparse_general_form(golden_dir, name):
         assert name in ("KB2", "SCORPION", "STANDATA")
 
 
+def test_two_level_blocking_option(monkeypatch):
+    """Paired Cholesky steps with K = 256 trailing updates (default from 48 blocks on; forced here at 9 and 16 blocks):
+    same factor as the one-level schedule up to rounding, same solve."""
+    rng = np.random.default_rng(21)
+    for m in (1100, 2048):
+        M = rng.standard_normal((m, m + 50))
+        B = M @ M.T + 0.5 * np.eye(m)
+        rhs = rng.standard_normal(m)
+        out = {}
+        for mode in ("0", "2"):
+            monkeypatch.setenv("IPM_TWO_LEVEL", mode)
+            with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+                z, nfix = sv.solve_linear(B, rhs)
+                out[mode] = (z.ravel(), sv.get_factor())
+            assert nfix == 0 and np.linalg.norm(B @ out[mode][0] - rhs) / np.linalg.norm(rhs) < 1e-10
+        assert rel(out["2"][1], out["0"][1]) < 1e-11
+        assert rel(out["2"][1], np.linalg.cholesky(B)) < 1e-11
+    A, b, c = synthetic_lp(1100, 2300, seed=3)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("IPM_TWO_LEVEL", mode)
+        with ipm.IpmSolver(A, b, c) as sv:
+            sv.init_state(0.0)
+            res[mode] = sv.solve(tol=1e-8, max_iter=200)
+    assert res["0"]["status"] == 1 and res["2"]["status"] == 1 and res["0"]["iterations"] == res["2"]["iterations"]
+    assert abs(res["0"]["objective"] - res["2"]["objective"]) <= 1e-9 * (1 + abs(res["0"]["objective"]))
+
+
 def test_normal_solve_entry(golden_dir):
     """ipm_normal_solve: (A diag(d) A^T) z = rhs with the handle's own A, dense and sparse, factor reuse."""
     rng = np.random.default_rng(8)

@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--workers", type=int, default=2, help="netlib: small LPs solved concurrently per GPU (1 = strictly one at a time)")
     ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],
                     help="netlib, N > 1: pull LPs from a shared counter (rendezvous store) or static LPT partition")
-    ap.add_argument("--start", default="reference", choices=["reference", "mehrotra"],
+    ap.add_argument("--start-point", dest="start", default="reference", choices=["reference", "mehrotra"],
                     help="netlib: start point; reference = x=s=y=1 (sparse_interior.py:193-200, parity mode), mehrotra = "
                          "Mehrotra's least-squares start (optional mode, not the reference's algorithm)")
     ap.add_argument("--regularize", type=float, default=0.0, help="netlib: Tikhonov shift (0 = reference-faithful)")

@@ -10,7 +10,8 @@ from oracle import ipm_oracle as O
 rng = np.random.default_rng(2026)
 bad = 0
 sizes = [(1, 3), (2, 2), (127, 300), (128, 256), (129, 257), (255, 700), (257, 513), (640, 900), (1000, 2100), (1023, 2047),
-         (1024, 2048), (1025, 2051), (1500, 1600), (2047, 4100), (2049, 4097), (2304, 4700), (3000, 6100)]
+         (1024, 2048), (1025, 2051), (1500, 1600), (2047, 4100), (2049, 4097), (2304, 4700), (3000, 6100),
+         (6200, 9000), (7000, 7100)]      # >= 48 blocks: the two-level factorization; sparse: RCM + tile envelope
 for (m, n) in sizes:
     for kind in ("dense", "sparse"):
         if kind == "dense":

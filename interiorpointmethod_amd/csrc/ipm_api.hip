@@ -42,7 +42,8 @@ struct ipm_handle {
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
     unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
-    int two_level = 1;                    // pair the Cholesky steps: K = 256 trailing updates (IPM_TWO_LEVEL=0 disables)
+    int group_steps = 0;                  // > 0: forced group size of the two-level schedule
+    int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
     int bulk_variant = 0;                 // 1: BK=32 tiles for the bulk trailing update (measured slower: 2.38 vs 2.26 ms)
     int crit_variant = 1;                 // smaller tiles / deeper K steps for the two critical-path GEMMs
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
@@ -315,6 +316,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
+    if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -608,9 +610,16 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     const bool la = h->lookahead != 0 && h->nblk > 2;
-    // measured: 16384 x 32768 factor 39.8 -> 35.0 ms, 8192 x 16384 7.85 -> 7.46 ms, but 4096 x 8192 2.21 -> 2.36 ms (half of
-    // its steps are bound by the pivot chain, which pairing lengthens): on from 48 blocks; IPM_TWO_LEVEL=2 forces it
-    const bool two_level = la && !use_env && ((h->two_level == 1 && h->nblk >= 48) || (h->two_level == 2 && h->nblk >= 8));
+    // group size of the two-level schedule.  Measured (factor, ms): 16384 x 32768: 39.7 / 34.9 / 33.4 / 32.9 / 32.5 for groups
+    // of 1 / 2 / 3 / 4 / 6; 8192 x 16384: 7.87 / 7.46 / 7.34 / 7.34 for 1 / 2 / 3 / 4; but 4096 x 8192: 2.21 -> 2.36 with groups
+    // of 2 (half of its steps are bound by the pivot chain, which grouping lengthens): on from 48 blocks.
+    // IPM_TWO_LEVEL=0 disables, IPM_GROUP_STEPS=n forces a group size (>= 8 blocks).
+    int gs = 1;
+    if (la && !use_env && h->two_level != 0) {
+        if (h->group_steps > 0) gs = h->nblk >= 8 ? h->group_steps : 1;
+        else if (h->nblk >= 96) gs = 4;
+        else if (h->nblk >= 48) gs = 3;
+    }
     hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
     const bool fs = la && h->flag_sync != 0;
     std::vector<unsigned> bulk_wgs(h->nblk, 0u);          // workgroups of the bulk update of each step
@@ -674,15 +683,17 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
         else HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
         if (!crit_flag) HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
-        // Two-level blocking (dense handles): steps are paired (2p, 2p+1).  The even step updates only the next block
-        // column (a window of K = 128 tiles) and DEFERS the rest of its trailing update; the odd step applies both at
-        // once with K = 256 -- the two panels are adjacent block columns of L, i.e. one k-contiguous operand -- so the
-        // trailing matrix, whose read-modify-write is what bounds a K = 128 update (16 flop/byte), is streamed once per
-        // pair instead of once per step.
-        const bool pair_first = two_level && (k % 2 == 0);
-        const bool pair_second = two_level && (k % 2 == 1);
-        if (pair_second) {                                          // operands: block columns k-1 and k, rows >= k+1
-            u.P = panel - NB; u.Q = panel - NB; u.K = 2 * NB;
+        // Two-level blocking (dense handles): the steps come in groups of `gs` block columns.  A step updates only the
+        // remaining columns of its group (a window of K = 128 tiles) and DEFERS the rest of its trailing update; the last
+        // step of the group applies all of them at once with K = 128 gs -- the group's panels are adjacent block columns
+        // of L, i.e. one k-contiguous operand -- so the trailing matrix, whose read-modify-write is what bounds a
+        // K = 128 update (16 flop/byte), is streamed once per group instead of once per step.
+        const int g0 = gs > 1 ? (k / gs) * gs : k;
+        const int gend = gs > 1 ? std::min(g0 + gs, h->nblk) : k + 1;      // group = block columns [g0, gend)
+        const bool grp_inner = gs > 1 && k + 1 < gend;              // not the last column of its group: window only
+        const bool grp_last = gs > 1 && !grp_inner;
+        if (grp_last && k > g0) {                                   // operands: block columns g0..k, rows >= k+1
+            u.P = panel - (int64_t)(k - g0) * NB; u.Q = u.P; u.K = (k - g0 + 1) * NB;
         }
         GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1), as 64x64 sub-tiles
         if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));      // 10 sub-tiles of 32x32
@@ -694,12 +705,14 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
             const int nt = rem / NB;
-            if (pair_first) {
-                // window: tiles (i, k+1), i >= k+2:  B(i,k+1) -= L(i,k) L(k+1,k)^T  -- a plain (nt-1) x 1 tile GEMM
+            if (grp_inner) {
+                // window: tiles (i, j), i >= k+2, k+1 <= j < gend:  B(i,j) -= L(i,k) L(j,k)^T as ONE rectangular GEMM.
+                // Inside the group it also touches a few tiles above the diagonal (i < j), which nobody reads.
+                const int wn = gend - (k + 1);
                 ub.P = panel + (int64_t)NB * h->mp; ub.Q = panel;
                 ub.C = h->B + (int64_t)(k + 2) * NB * h->mp + (int64_t)(k + 1) * NB;
-                ub.M = rem - NB; ub.N = NB; ub.lower = 0;
-                if (fs) { bulk_wgs[k] = (unsigned)(nt - 1); ub.signal = h->d_bulk_done + k; }
+                ub.M = rem - NB; ub.N = std::min(wn * NB, rem); ub.lower = 0;
+                if (fs) { bulk_wgs[k] = (unsigned)((ub.M / NB) * (ub.N / NB)); ub.signal = h->d_bulk_done + k; }
                 HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb)));
                 HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
                 continue;

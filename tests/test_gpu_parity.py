@@ -435,31 +435,32 @@ def test_new_interior_sparse_general_form(golden_dir, name):
 
 
 def test_two_level_blocking_option(monkeypatch):
-    """Paired Cholesky steps with K = 256 trailing updates (default from 48 blocks on; forced here at 9 and 16 blocks):
-    same factor as the one-level schedule up to rounding, same solve."""
+    """Grouped Cholesky steps with K = 128*gs trailing updates (default: groups of 2 from 48 blocks on; forced here at 9
+    and 16 blocks with groups of 2, 3 and 4, 3 not dividing the block count): same factor as the one-level schedule up
+    to rounding, same solve."""
     rng = np.random.default_rng(21)
     for m in (1100, 2048):
         M = rng.standard_normal((m, m + 50))
         B = M @ M.T + 0.5 * np.eye(m)
         rhs = rng.standard_normal(m)
         out = {}
-        for mode in ("0", "2"):
-            monkeypatch.setenv("IPM_TWO_LEVEL", mode)
+        for gs in ("1", "2", "3", "4"):
+            monkeypatch.setenv("IPM_GROUP_STEPS", gs)
             with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
                 z, nfix = sv.solve_linear(B, rhs)
-                out[mode] = (z.ravel(), sv.get_factor())
-            assert nfix == 0 and np.linalg.norm(B @ out[mode][0] - rhs) / np.linalg.norm(rhs) < 1e-10
-        assert rel(out["2"][1], out["0"][1]) < 1e-11
-        assert rel(out["2"][1], np.linalg.cholesky(B)) < 1e-11
+                out[gs] = (z.ravel(), sv.get_factor())
+            assert nfix == 0 and np.linalg.norm(B @ out[gs][0] - rhs) / np.linalg.norm(rhs) < 1e-10
+            assert rel(out[gs][1], out["1"][1]) < 1e-11
+        assert rel(out["4"][1], np.linalg.cholesky(B)) < 1e-11
     A, b, c = synthetic_lp(1100, 2300, seed=3)
     res = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("IPM_TWO_LEVEL", mode)
+    for gs in ("1", "2", "4"):
+        monkeypatch.setenv("IPM_GROUP_STEPS", gs)
         with ipm.IpmSolver(A, b, c) as sv:
             sv.init_state(0.0)
-            res[mode] = sv.solve(tol=1e-8, max_iter=200)
-    assert res["0"]["status"] == 1 and res["2"]["status"] == 1 and res["0"]["iterations"] == res["2"]["iterations"]
-    assert abs(res["0"]["objective"] - res["2"]["objective"]) <= 1e-9 * (1 + abs(res["0"]["objective"]))
+            res[gs] = sv.solve(tol=1e-8, max_iter=200)
+        assert res[gs]["status"] == 1 and res[gs]["iterations"] == res["1"]["iterations"]
+        assert abs(res[gs]["objective"] - res["1"]["objective"]) <= 1e-9 * (1 + abs(res["1"]["objective"]))
 
 
 def test_normal_solve_entry(golden_dir):

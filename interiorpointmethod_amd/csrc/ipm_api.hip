@@ -682,6 +682,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         // (observed at m = 16384 with 254 pollers).  Only launches that leave most CUs untouched may poll.
         const bool crit_flag = fs && rem > NB && tb_wgs <= 64;
         if (crit_flag) tc.signal = h->d_bulk_done + h->nblk + k;
+        // NOTE the panel solve is IN PLACE (C = P): a workgroup must own whole rows, i.e. BN == N == 128.  Tiles narrower
+        // than the panel (tried: 16 workgroups of 32 x 32) race -- one workgroup overwrites columns another still reads.
         if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
         else HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
         if (!crit_flag) HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));

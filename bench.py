@@ -281,6 +281,14 @@ def main():
                                 "frac_of_fp64_mfma_peak": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12 / PEAK_FP64_MFMA_TFLOPS},
             "objective_after_last_block": st["objective"],
         }
+        # guard against a fast-but-wrong kernel variant: 20 iterations from the start point of the default LP give
+        # c^T x = -376.12529405 (the LP converges to -376.1254474176 after 24); checked when the last block is a full one
+        if (m, n) == (M_DEFAULT, N_DEFAULT) and args.steps % RESET_EVERY == 0:
+            ok = abs(st["objective"] - (-376.12529405)) <= 1e-6 * 376.0
+            out["objective_check"] = "ok" if ok else "MISMATCH"
+            if not ok:
+                print("bench: objective after %d iterations is %.12e, expected -3.7612529405e+02" % (RESET_EVERY, st["objective"]),
+                      file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, b, c)
         print(json.dumps(out))

@@ -17,7 +17,11 @@ collective; value = N*K / max-over-ranks time  (weak scaling).
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (the dominant kernel,
 the fp64-MFMA A D^2 A^T contraction, timed with HIP events on the solver's stream inside the
 timed region) and `cpu_baseline` (the NumPy normal-equations oracle on the host cores,
-bounded sample, rank 0 at N=1 only).
+bounded sample, rank 0 at N=1 only), `cpu_baseline_reference_algorithm` (one iteration of the
+reference's OWN algorithm -- dense (m+2n) KKT matrix, two LAPACK gesv, main.py:13-21/185-244 --
+restated by the oracle, same rank/N) and `netlib`: the second half of BASELINE.json's metric,
+Netlib LPs/s over the 26-LP parity set on this GPU with its own `roofline` and `cpu_baseline`
+(`--workload netlib` runs the full suite, sharded over the ranks, with the same keys).
 """
 import argparse
 import json
@@ -33,6 +37,63 @@ RESET_EVERY = 20
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense fp64 matrix peak
 
 
+def kernel_source_sha():
+    """sha256 (first 16 hex) of the sources the dominant kernel is built from: a PMC pass collected for another
+    version of the kernel is refused (profiles/*_pmc_form_kernel.json carries the sha it was collected with)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("gemm_nt_f64.h",):
+        with open(os.path.join(ROOT, "interiorpointmethod_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def load_traffic(m, n):
+    """(traffic bytes per launch | None, note).  HBM-side bytes of the dominant kernel from the newest committed PMC
+    pass (tools/pmc_form_kernel.py), accepted only for the same problem size AND the same kernel source."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_form_kernel.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        best = (f, d)
+    if best is None:
+        return None, "no PMC pass committed"
+    f, d = best
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return None, "stale: %s was collected for kernel source %s, current is %s" % (
+            os.path.basename(f), d.get("kernel_source_sha"), kernel_source_sha())
+    if tuple(d.get("shape", ())) != (m, n):
+        return None, "%s is for shape %s" % (os.path.basename(f), d.get("shape"))
+    return d["derived"]["traffic_bytes_per_launch"], "from %s (rocprofv3 --pmc, separate passes)" % os.path.basename(f)
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline_reference_algorithm(A, b, c):
+    """ONE iteration of the reference's own dense algorithm (assemble the (m+2n)^2 KKT matrix, two LAPACK gesv:
+    main.py:13-21, 185-244) as restated by oracle.iterate(method="full"), from the start point, on the host."""
+    from oracle import ipm_oracle as O
+    m, n = A.shape
+    x, y, s = O.initial_point(m, n, 0.0)
+    t0 = time.perf_counter()
+    O.iterate(A, b, c, x, y, s, method="full")
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "iterations/s", "cores": _blas_threads(), "kind": "port",
+            "sample": "1 iteration of oracle.iterate(method='full'): dense KKT matrix of order m+2n = %d, two LAPACK "
+                      "gesv (the reference's algorithm, main.py:13-21/185-244), %.1f s; survey container (8 Xeon "
+                      "cores, reference verbatim): 106.7 s/iteration at 4096x8192 (BASELINE.md 2.2)" % (m + 2 * n, dt)}
+
+
 def cpu_baseline(A, b, c, budget_s=20.0, max_its=6):
     """Oracle (NumPy normal equations + LAPACK Cholesky) timed on the host: bounded sample."""
     import numpy as np
@@ -45,24 +106,21 @@ def cpu_baseline(A, b, c, budget_s=20.0, max_its=6):
         x, y, s, _ = O.iterate(A, b, c, x, y, s, method="normal")
         its += 1
     dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": its / dt, "unit": "iterations/s", "cores": int(threads), "kind": "port",
-            "sample": "%d iterations of oracle.iterate(method='normal') (NumPy (A*d)@A.T + LAPACK potrf) "
-                      "on the same %dx%d LP from the start point, %.1f s, host has %d logical CPUs" % (
-                          its, m, n, dt, os.cpu_count() or 0)}
+    return {"value": its / dt, "unit": "iterations/s", "cores": _blas_threads(), "kind": "port",
+            "sample": "%d iterations of oracle.iterate(method='normal') (NumPy (A*d)@A.T + LAPACK potrf: the SAME "
+                      "normal-equations algorithm the GPU runs, not the reference's full-KKT LU -- that one is "
+                      "cpu_baseline_reference_algorithm) on the same %dx%d LP from the start point, %.1f s, host has "
+                      "%d logical CPUs" % (its, m, n, dt, os.cpu_count() or 0)}
 
 
-def _dist_setup(local_rank, world):
-    """(dist module or None, device index, device for the scalar reductions).  One rank per GPU over RCCL; the
-    environment IPM_BENCH_BACKEND=gloo + IPM_BENCH_ONE_DEVICE=1 rehearses the multi-rank code path on a one-GPU box
-    (every rank on device 0, CPU collectives)."""
+def _dist_setup(local_rank, world, want_store=False):
+    """(dist module or None, device index, device for the scalar reductions, store or None).  One rank per GPU over
+    RCCL; the environment IPM_BENCH_BACKEND=gloo + IPM_BENCH_ONE_DEVICE=1 rehearses the multi-rank code path on a
+    one-GPU box (every rank on device 0, CPU collectives).  want_store: a TCPStore (public API) for the
+    self-scheduling counter of the batched mode, or None when it cannot be set up on every rank."""
     import torch
     if world <= 1:
-        return None, local_rank, "cuda"
+        return None, local_rank, "cuda", None
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("IPM_BENCH_BACKEND", "nccl")
@@ -70,9 +128,22 @@ def _dist_setup(local_rank, world):
     torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-        return dist, dev, "cuda"
-    dist.init_process_group(backend=backend)
-    return dist, dev, "cpu"
+        red = "cuda"
+    else:
+        dist.init_process_group(backend=backend)
+        red = "cpu"
+    store = None
+    if want_store:
+        from interiorpointmethod_amd import batch
+        try:
+            store = batch.make_store(dist.get_rank(), world, timeout_s=60)
+        except Exception as e:          # port in use, ...: fall back to the static partition -- on EVERY rank
+            print("bench: no scheduling store on rank %d (%s)" % (dist.get_rank(), e), file=sys.stderr)
+        ok = torch.tensor([1 if store is not None else 0], dtype=torch.int32, device=red)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            store = None
+    return dist, dev, red, store
 
 
 PARITY_SET = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "GROW7", "KB2", "MAROS-R7", "SC105",
@@ -80,23 +151,23 @@ PARITY_SET = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "
               "STOCFOR1", "STOCFOR2", "STOCFOR3", "TRUSS", "WOODW"]
 
 
-def netlib_main(args):
-    """Batched-LP mode (BASELINE.json configs[3]): the Netlib fixtures sharded over the ranks, one LP per
-    GPU at a time, a single RCCL all-gather of the statistics records at the end."""
+def load_netlib(which, max_m=1 << 30):
+    """(names, problems, algorithmic flops per iteration) of the committed Netlib fixtures.  which: "all" (73 valid
+    benchmarks/ files), "parity" (the 26 the reference converges on), "general" (benchmarks_full through the
+    general-form front end; conversion on the host, untimed)."""
     import glob
     import numpy as np
-    import torch
-    from interiorpointmethod_amd import batch
+    from scipy import sparse
     from interiorpointmethod_amd.matio import load_npz_problem
+    from interiorpointmethod_amd.workloads import flops_per_iteration
+    names, probs, flops = [], [], []
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist, dev, red_dev = _dist_setup(local_rank, world)
-    names, probs, costs = [], [], []
-    if args.netlib_set == "general":
-        # the reference's benchmarks_full files (general form) through the front end: conversion on the host, untimed
-        from scipy import sparse
+    def add(nm, A, b, c):
+        A = sparse.csc_matrix(A)
+        names.append(nm); probs.append((A, b, c))
+        flops.append(flops_per_iteration(A.shape[0], A.shape[1], float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2))))
+
+    if which == "general":
         from interiorpointmethod_amd import general_form as G
         for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "general", "*.npz"))):
             z = np.load(f)
@@ -109,34 +180,78 @@ def netlib_main(args):
             A, b, c, _ = G.standard_form(z["c"], Aeq=mat("Aeq"), beq=z["beq"] if "beq" in z.files else None,
                                          Aineq=mat("Aineq"), bineq=z["bineq"] if "bineq" in z.files else None,
                                          lb=z["lb"], ub=z["ub"])
-            if A.shape[0] > args.max_m:
-                continue
-            names.append(os.path.basename(f)[:-4])
-            probs.append((sparse.csc_matrix(A), b, c))
-            costs.append(batch.predicted_cost(A.shape[0], A.shape[1]))
-    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netlib", "*.npz")) if args.netlib_set != "general" else []):
+            if A.shape[0] <= max_m:
+                add(os.path.basename(f)[:-4], A, b, c)
+        return names, probs, flops
+    for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netlib", "*.npz"))):
         nm = os.path.basename(f)[:-4]
-        if args.netlib_set == "parity" and nm not in PARITY_SET:
+        if which == "parity" and nm not in PARITY_SET:
             continue
         A, b, c, cTlb, valid = load_npz_problem(f)
-        if not valid or A.shape[0] > args.max_m:
-            continue
-        names.append(nm)
-        probs.append((A, b, c))
-        colnnz = np.diff(A.indptr).astype(np.float64)
-        costs.append(batch.predicted_cost(A.shape[0], A.shape[1]))     # dense-A contraction today
-    # warm-up: one small solve per rank (library load, first-launch costs) outside the timed region
-    batch.solve_one(probs[names.index("AFIRO")] if "AFIRO" in names else probs[0], device=dev)
+        if valid and A.shape[0] <= max_m:
+            add(nm, A, b, c)
+    return names, probs, flops
+
+
+def netlib_roofline(names, probs, flops, rec, elapsed, world):
+    """Roofline view of a batched run.  Algorithmic flops of an LP = iterations x (sum_j nnz(A[:,j])^2 + m^3/3 + 4m^2
+    + 12 nnz-ish terms) (SURVEY 8d with the sparse contraction count); the suite is NOT flop bound -- every iteration
+    is a chain of dependent launches (measured cost model 0.1 ms + 0.11 ms per 128-row block, batch.predicted_cost) --
+    so the latency model's prediction is printed beside the MFMA fraction."""
+    import numpy as np
+    its = rec[:, 2]
+    total = float(np.sum(its * np.array(flops)))
+    nblk = np.array([(p[0].shape[0] + 127) // 128 for p in probs], dtype=np.float64)
+    chain_s = float(np.sum(its * (0.1 + 0.11 * nblk)) * 1e-3)
+    ach = total / elapsed / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS * max(world, 1), "unit": "TFLOP/s",
+            "frac": ach / (PEAK_FP64_MFMA_TFLOPS * max(world, 1)), "traffic": None,
+            "flops_total": total, "iterations_total": int(its.sum()),
+            "note": "sum over LPs of iterations x (sum_j nnz_j^2 + m^3/3 + 4 m^2 + 12 m n) / wall / (78.6 TFLOP/s x GPUs); "
+                    "the suite is bound by the per-iteration launch chain, not by flops",
+            "latency_floor": {"model": "iterations x (0.1 ms + 0.11 ms per 128-row block) summed over the LPs, one LP at a "
+                                       "time on one GPU (round-1 measurement, batch.predicted_cost)",
+                              "chain_seconds_one_gpu": chain_s, "measured_wall_seconds": elapsed,
+                              "largest_lp_seconds": float(rec[:, 7].max())}}
+
+
+def netlib_cpu_baseline(names, probs, budget_s=15.0, tol_gap=None, max_iter=300):
+    """The oracle (normal equations + guarded Cholesky, the algorithm the GPU runs) over a BOUNDED sample of the same
+    set on the host: smallest LPs first until the time budget is spent, one process, BLAS threads as configured."""
+    import numpy as np
+    from oracle import ipm_oracle as O
+    order = sorted(range(len(names)), key=lambda i: (probs[i][0].shape[0] * probs[i][0].shape[1], names[i]))
+    done, conv, t0 = [], 0, time.perf_counter()
+    for i in order:
+        if time.perf_counter() - t0 > budget_s:
+            break
+        A, b, c = probs[i]
+        x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=1.0, method="normal", max_iter=max_iter, tol_gap=tol_gap)
+        done.append(names[i]); conv += int(info["status"] == O.STATUS_OK)
+    dt = time.perf_counter() - t0
+    return {"value": conv / dt, "unit": "LPs/s", "cores": _blas_threads(), "kind": "port",
+            "sample": "oracle.solve(method='normal') on the %d smallest LPs of the set (%s ... %s), %d converged, %.1f s, "
+                      "one process; reference verbatim loop in the survey container: 26 LPs in 603 s = 0.043 LPs/s "
+                      "per worker (BASELINE.md 2.4)" % (len(done), done[0] if done else "-", done[-1] if done else "-",
+                                                        conv, dt),
+            "sample_names": done}
+
+
+def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, workers=2, schedule="dynamic",
+               start="reference", regularize=0.0, general=False):
+    """Timed batched solve of the set -> (records, elapsed seconds incl. the gather, max over ranks)."""
+    import torch
+    from interiorpointmethod_amd import batch
+    costs = [batch.predicted_cost(p[0].shape[0], p[0].shape[1]) for p in probs]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist,
+    rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist, store=store,
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
-                             tol=1e-8, regularize=args.regularize, workers=args.workers,
-                             schedule=args.schedule, start=args.start,
+                             tol=1e-8, regularize=regularize, workers=workers, schedule=schedule, start=start,
                              # the general-form driver's own settings: e3 = 1e-6, at most 999 iterations (main.py:1088-1127)
-                             **(dict(max_iter=999, tol_gap=1e-6) if args.netlib_set == "general" else dict(max_iter=300)))
+                             **(dict(max_iter=999, tol_gap=1e-6) if general else dict(max_iter=300)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -145,20 +260,43 @@ def netlib_main(args):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    return rec, elapsed
+
+
+def netlib_main(args):
+    """Batched-LP mode (BASELINE.json configs[3]): the Netlib fixtures sharded over the ranks (self-scheduled from a
+    shared counter, or a static LPT partition), a single RCCL all-gather of the statistics records at the end."""
+    import torch
+    from interiorpointmethod_amd import batch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist, dev, red_dev, store = _dist_setup(local_rank, world, want_store=(args.schedule == "dynamic"))
+    names, probs, flops = load_netlib(args.netlib_set, args.max_m)
+    general = args.netlib_set == "general"
+    # warm-up: one small solve per rank (library load, first-launch costs) outside the timed region
+    batch.solve_one(probs[names.index("AFIRO")] if "AFIRO" in names else probs[0], device=dev)
+    rec, elapsed = run_netlib(names, probs, flops, dev, dist=dist, red_dev=red_dev, store=store, workers=args.workers,
+                              schedule=args.schedule, start=args.start, regularize=args.regularize, general=general)
     if rank == 0:
         summ = batch.summarize(rec)
+        sched = "one rank" if world <= 1 else ("self-scheduled from a shared counter (TCPStore)"
+                                               if (args.schedule == "dynamic" and store is not None) else "static LPT partition")
         out = {"metric": "Netlib LPs/sec (benchmarks_full/ general-form suite, batched, tol=1e-8, e3=1e-6, cap 999)"
-                         if args.netlib_set == "general" else "Netlib LPs/sec (benchmarks/ suite, batched, tol=1e-8, cap 300)",
+                         if general else "Netlib LPs/sec (benchmarks/ suite, batched, tol=1e-8, cap 300)",
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
                "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
                "config": {"workload": "Netlib %s set, %d LPs over %d GPU(s), %s; per GPU %d LP(s) in flight on separate streams" % (
-                   args.netlib_set, len(names), max(world, 1),
-                   "one rank" if world <= 1 else ("self-scheduled from the rendezvous store" if args.schedule == "dynamic"
-                                                  else "static LPT partition"), max(1, args.workers))},
+                   args.netlib_set, len(names), max(world, 1), sched, max(1, args.workers))},
+               "roofline": netlib_roofline(names, probs, flops, rec, elapsed, world),
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize, "start_point": args.start,
                "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
                           for r in rec}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = netlib_cpu_baseline(names, probs, tol_gap=1e-6 if general else None,
+                                                      max_iter=999 if general else 300)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -172,6 +310,7 @@ def main():
     ap.add_argument("--m", type=int, default=M_DEFAULT)
     ap.add_argument("--n", type=int, default=N_DEFAULT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-netlib", action="store_true", help="dense workload: skip the Netlib leg of the default line")
     ap.add_argument("--workload", default="dense", choices=["dense", "netlib"],
                     help="dense: IPM iterations/s on the synthetic LP (default, the headline metric); "
                          "netlib: LPs/s over the committed Netlib fixtures, sharded over the ranks")
@@ -198,7 +337,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist, dev, red_dev = _dist_setup(local_rank, world)
+    dist, dev, red_dev, _ = _dist_setup(local_rank, world)
     ngpu = max(world, 1)
     if args.gpus != ngpu and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -250,13 +389,7 @@ def main():
         form_ms = phases[0] / K
         flops_form = float(m) * m * n                       # lower-triangle SYRK, SURVEY 8(d)
         achieved = flops_form / (form_ms * 1e-3) / 1e12 if form_ms > 0 else 0.0
-        traffic = None          # HBM bytes per launch of the dominant kernel: PMC pass collected separately
-        try:                    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_form_kernel.json)
-            if (m, n) == (M_DEFAULT, N_DEFAULT):
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_form_kernel.json")) as fh:
-                    traffic = json.load(fh)["derived"]["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic, traffic_src = load_traffic(m, n)      # HBM-side bytes per launch: PMC pass collected separately
         out = {
             "metric": "IPM iterations/sec (m=%d,n=%d dense LP)" % (m, n),
             "value": its_per_s, "unit": "iterations/s", "n_gpus": ngpu, "steps": K, "warmup": args.warmup,
@@ -267,10 +400,11 @@ def main():
                        "reset_every": RESET_EVERY},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_note": "L2<->fabric bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE, "
-                                         "gfx950 correction); 0.34 GB algorithmic; with eight private L2s the floor for this "
-                                         "tiling is ~1.1 GB (each XCD reads half the row panels of A); part of it is served by "
-                                         "the 256 MB Infinity Cache, so HBM bytes are lower; <1 TB/s either way: MFMA-bound",
+                         "traffic_source": traffic_src,
+                         "traffic_note": "L2<->fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), null when "
+                                         "the committed PMC pass was collected for another kernel source or size; algorithmic "
+                                         "bytes 8mn + 4m^2",
+                         "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
                          "kernel": "gemm_nt_f64_kernel<128,128,16,2,2> (B = A diag(d) A^T)",
                          "flops_per_launch": flops_form, "avg_launch_ms": form_ms},
             "phases_ms_per_step": {"form": form_ms, "factor": phases_all[1] / KB, "trisolve": phases_all[2] / KB,
@@ -281,16 +415,50 @@ def main():
                                 "frac_of_fp64_mfma_peak": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12 / PEAK_FP64_MFMA_TFLOPS},
             "objective_after_last_block": st["objective"],
         }
-        # guard against a fast-but-wrong kernel variant: 20 iterations from the start point of the default LP give
-        # c^T x = -376.12529405 (the LP converges to -376.1254474176 after 24); checked when the last block is a full one
-        if (m, n) == (M_DEFAULT, N_DEFAULT) and args.steps % RESET_EVERY == 0:
-            ok = abs(st["objective"] - (-376.12529405)) <= 1e-6 * 376.0
-            out["objective_check"] = "ok" if ok else "MISMATCH"
+        # guard against a fast-but-wrong kernel variant (checked when the last block is a full one): at the default
+        # size the objective after RESET_EVERY iterations is compared with the REFERENCE's own trajectory
+        # (tests/golden/dense_syn_4096x8192.npz, generated by importing the reference); at other sizes with the same
+        # iterations under the one-level factorization (IPM_TWO_LEVEL=0) on a second handle
+        if args.steps % RESET_EVERY == 0:
+            fx = os.path.join(ROOT, "tests", "golden", "dense_syn_%dx%d.npz" % (m, n))
+            if os.path.exists(fx):
+                ref_obj = float(np.load(fx)["objective_after_iteration"][RESET_EVERY - 1])
+                ok = abs(st["objective"] - ref_obj) <= 1e-6 * max(1.0, abs(ref_obj))
+                out["objective_check"] = "ok" if ok else "MISMATCH"
+                out["objective_check_against"] = "reference trajectory, iteration %d: %.12e" % (RESET_EVERY, ref_obj)
+            else:
+                sv.close()
+                os.environ["IPM_TWO_LEVEL"] = "0"
+                sv1 = ipm.IpmSolver(A, b, c, device=dev)
+                sv1.init_state(0.0)
+                st1 = sv1.iterate(RESET_EVERY)
+                ref_obj = st1["objective"]
+                sv1.close()
+                del os.environ["IPM_TWO_LEVEL"]
+                ok = abs(st["objective"] - ref_obj) <= 1e-9 * max(1.0, abs(ref_obj))
+                out["objective_check"] = "ok" if ok else "MISMATCH"
+                out["objective_check_against"] = "same %d iterations with IPM_TWO_LEVEL=0: %.12e" % (RESET_EVERY, ref_obj)
             if not ok:
-                print("bench: objective after %d iterations is %.12e, expected -3.7612529405e+02" % (RESET_EVERY, st["objective"]),
+                print("bench: objective after %d iterations is %.12e, expected %.12e" % (RESET_EVERY, st["objective"], ref_obj),
                       file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, b, c)
+            if (m, n) == (M_DEFAULT, N_DEFAULT):
+                out["cpu_baseline_reference_algorithm"] = cpu_baseline_reference_algorithm(A, b, c)
+        if world == 1 and not args.no_netlib and (m, n) == (M_DEFAULT, N_DEFAULT):
+            # second half of the headline metric on the same GPU: the 26-LP parity set, two LPs in flight
+            sv.close()
+            from interiorpointmethod_amd import batch
+            names, probs, flops = load_netlib("parity")
+            batch.solve_one(probs[names.index("AFIRO")], device=dev)         # warm-up
+            rec, el = run_netlib(names, probs, flops, dev, workers=2)
+            summ = batch.summarize(rec)
+            out["netlib"] = {"metric": "Netlib LPs/sec (26-LP parity set of benchmarks/, tol=1e-8, cap 300, 2 LPs in flight)",
+                             "value": summ["converged"] / el, "unit": "LPs/s", "n_gpus": 1, "wall_seconds": el,
+                             "summary": summ, "roofline": netlib_roofline(names, probs, flops, rec, el, 1),
+                             "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)} for r in rec}}
+            if not args.no_cpu_baseline:
+                out["netlib"]["cpu_baseline"] = netlib_cpu_baseline(names, probs)
         print(json.dumps(out))
     sv.close()
     if dist is not None:

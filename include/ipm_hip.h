@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IPM_ABI_VERSION 1
+#define IPM_ABI_VERSION 2
 
 /* return codes */
 enum {
@@ -55,9 +55,16 @@ enum {
     /* The Cholesky look-ahead hands work between its two streams through device counters polled inside kernels.
      * That is only safe while the handle's streams own their hardware queues: when several handles are driven
      * concurrently on one GPU (more streams than hardware queues), a polling kernel can sit in front of its own
-     * producer in a shared queue.  Set this flag for such handles: stream events are used instead (slower per
-     * step, never blocks). */
-    IPM_FLAG_NO_DEVICE_POLLING = 1
+     * producer in a shared queue.  The library protects itself: it counts the live handles per device and uses
+     * stream events whenever more than one exists, and a poll that still times out (bounded spin) is not an error --
+     * the affected call is rolled back and repeated with events, and the handle keeps events from then on
+     * (ipm_get_schedule reports it).  This flag forces events from the start (slower per step, never polls). */
+    IPM_FLAG_NO_DEVICE_POLLING = 1,
+    /* ipm_solve switches the 1e-14 Tikhonov shift on by itself when the FIRST factorization of a solve had to guard
+     * more than 5 % of its pivots (A has that many dependent rows: the QAP family of Netlib, 9-16 %; no other Netlib
+     * file exceeds 2.7 %) and restarts the solve from its start state; the guard alone stalls there.
+     * Reported in ipm_stats.auto_regularized.  This flag keeps the shift off. */
+    IPM_FLAG_NO_AUTO_REGULARIZE = 2
 };
 
 typedef struct ipm_handle ipm_handle;
@@ -79,7 +86,7 @@ typedef struct ipm_stats {
     int32_t status;          /* IPM_STATUS_* */
     int32_t iterations;      /* k: completed predictor-corrector steps */
     int32_t pivots_fixed;    /* total Cholesky pivots replaced by the guard */
-    int32_t reserved;
+    int32_t auto_regularized; /* 1: ipm_solve switched the Tikhonov shift on (IPM_FLAG_NO_AUTO_REGULARIZE) */
     double objective;        /* c^T x                                        main.py:815 */
     double rp_norm;          /* ||Ax-b||_2 */
     double rd_norm;          /* ||A^T y + s - c||_2 */
@@ -89,7 +96,19 @@ typedef struct ipm_stats {
     double alpha_aff_p, alpha_aff_d;     /* predictor ratio tests    main.py:305-322 */
     double alpha_p, alpha_d;             /* damped step lengths      main.py:604-626 */
     double solve_ms;         /* device time of the last ipm_solve/ipm_iterate (HIP events) */
+    double objective_last_finite; /* last finite c^T x seen by the stop test: what new_interior_sparse returns
+                                     when the iterate goes NaN (main.py:1227-1233) */
 } ipm_stats;
+
+/* One record per completed iteration (the reference prints such a line: main.py:808-809, :1186).  objective, norms
+ * and gap describe the iterate the iteration STARTED from (they come from its stop test), the step data what it did. */
+typedef struct ipm_iter_record {
+    int32_t k;               /* 0-based iteration index */
+    int32_t pivots_fixed;    /* cumulative guarded pivots after this iteration's factorization */
+    double objective, rp_norm, rd_norm, gap, mu, sigma;
+    double alpha_aff_p, alpha_aff_d, alpha_p, alpha_d;
+} ipm_iter_record;
+#define IPM_HISTORY_CAPACITY 1024   /* ring: the most recent records are kept */
 
 /* ---- library ---------------------------------------------------------------------- */
 int ipm_abi_version(void);
@@ -140,16 +159,30 @@ int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, double* dy, d
 
 /* ---- solver seam ------------------------------------------------------------------- */
 /* Run exactly n_steps predictor-corrector iterations from the current state.  The stop
- * test is evaluated (stats) but not acted on: this is the benchmark entry point. */
+ * test is evaluated (stats) but not acted on: this is the benchmark entry point.  The residuals and the stop test
+ * are evaluated once more after the last step, so objective / norms / gap in `stats` describe the state
+ * ipm_get_state returns (step lengths, mu_aff and sigma are those of the last step taken). */
 int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats);
 /* Loop of interior_sparse: stop test first, then one iteration, until the test fails or
  * max_iter iterations were taken.  tol_p/tol_d/tol_gap = e1/e2/e3 of main.py:772-774. */
 int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t max_iter,
               ipm_stats* stats);
+/* Per-iteration records of the last ipm_solve / ipm_iterate, oldest first: min(iterations, IPM_HISTORY_CAPACITY,
+ * capacity) records are written to `out` (host) and their number to *count. */
+int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32_t* count);
+/* How the handle schedules its factorization (tests and diagnostics): out[0] = 128-row blocks, out[1] = group size
+ * of the two-level Cholesky (1 = one-level), out[2] = 1 when the 1024-row grouped triangular solves are used,
+ * out[3] = 1 while cross-stream hand-offs poll device counters (0: stream events), out[4] / out[5] = bulk trailing
+ * updates of the last factorization that signalled a counter / recorded an event, out[6] = 1 when the tile envelope
+ * of a sparse handle is exploited, out[7] = live handles on this device, out[8] = poll time-outs recovered so far,
+ * out[9] = 1 when the fused single-workgroup small-LP path serves this handle. */
+int ipm_get_schedule(ipm_handle* h, int32_t out[10]);
 
 /* ---- linear-solve seam (main.py:176-182) and kernel-level entry points ------------- */
-/* Solve B z = rhs for a dense SPD m x m host matrix by the blocked guarded Cholesky
- * (m = the handle's m).  z may alias rhs.  pivots_fixed may be NULL. */
+/* Solve B z = rhs for a dense SYMMETRIC POSITIVE (SEMI)DEFINITE m x m host matrix by the blocked guarded Cholesky
+ * (m = the handle's m; only the lower triangle is read).  The reference's solve_linear takes any square matrix
+ * (LU); this seam is the normal-equations one, where the matrix is A D^2 A^T -- a general matrix is not accepted.
+ * z may alias rhs.  pivots_fixed may be NULL. */
 int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, const double* rhs, double* z,
                      int32_t* pivots_fixed);
 /* Solve (A diag(d) A^T) z = rhs with the handle's own A: forms the normal matrix on the device (d on the host,

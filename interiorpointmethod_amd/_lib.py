@@ -18,13 +18,16 @@ EXPORTS = [
     "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
-    "ipm_iterate", "ipm_solve", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
+    "ipm_iterate", "ipm_solve", "ipm_get_history", "ipm_get_schedule", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
     "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps",
 ]
 
 IPM_OK = 0
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NAN = 0, 1, 2, 3
 FLAG_NO_DEVICE_POLLING = 1      # include/ipm_hip.h: IPM_FLAG_NO_DEVICE_POLLING
+FLAG_NO_AUTO_REGULARIZE = 2     # include/ipm_hip.h: IPM_FLAG_NO_AUTO_REGULARIZE
+ABI_VERSION = 2
+HISTORY_CAPACITY = 1024         # IPM_HISTORY_CAPACITY
 ERR_INVALID_INPUT = -6
 
 
@@ -46,14 +49,23 @@ class Options(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("status", C.c_int32), ("iterations", C.c_int32), ("pivots_fixed", C.c_int32),
-                ("reserved", C.c_int32), ("objective", C.c_double), ("rp_norm", C.c_double),
+                ("auto_regularized", C.c_int32), ("objective", C.c_double), ("rp_norm", C.c_double),
                 ("rd_norm", C.c_double), ("gap", C.c_double), ("b_norm", C.c_double),
                 ("c_norm", C.c_double), ("mu", C.c_double), ("mu_aff", C.c_double),
                 ("sigma", C.c_double), ("alpha_aff_p", C.c_double), ("alpha_aff_d", C.c_double),
-                ("alpha_p", C.c_double), ("alpha_d", C.c_double), ("solve_ms", C.c_double)]
+                ("alpha_p", C.c_double), ("alpha_d", C.c_double), ("solve_ms", C.c_double),
+                ("objective_last_finite", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class IterRecord(C.Structure):
+    """ipm_iter_record: one per completed iteration (the line the reference prints, main.py:808-809, :1186)."""
+    _fields_ = [("k", C.c_int32), ("pivots_fixed", C.c_int32), ("objective", C.c_double), ("rp_norm", C.c_double),
+                ("rd_norm", C.c_double), ("gap", C.c_double), ("mu", C.c_double), ("sigma", C.c_double),
+                ("alpha_aff_p", C.c_double), ("alpha_aff_d", C.c_double), ("alpha_p", C.c_double),
+                ("alpha_d", C.c_double)]
 
 
 _lib = None
@@ -105,6 +117,8 @@ def load():
     lib.ipm_newton_direction.argtypes = [vp, C.c_int, pd, pd, pd, C.POINTER(Stats)]
     lib.ipm_iterate.argtypes = [vp, i32, C.POINTER(Stats)]
     lib.ipm_solve.argtypes = [vp, dbl, dbl, dbl, i32, C.POINTER(Stats)]
+    lib.ipm_get_history.argtypes = [vp, C.POINTER(IterRecord), i32, C.POINTER(i32)]
+    lib.ipm_get_schedule.argtypes = [vp, C.POINTER(i32)]
     lib.ipm_solve_linear.argtypes = [vp, pd, i64, pd, pd, C.POINTER(i32)]
     lib.ipm_normal_solve.argtypes = [vp, pd, pd, pd, C.c_int, C.POINTER(i32)]
     lib.ipm_form_normal_matrix.argtypes = [vp, pd, pd, i64]

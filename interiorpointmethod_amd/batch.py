@@ -45,6 +45,22 @@ def lpt_partition(costs, world):
     return shards
 
 
+def _error_info(status=STATUS_ERROR):
+    nan = float("nan")
+    return dict(status=status, iterations=0, objective=nan, rp=nan, rd=nan, gap=nan, pivots_fixed=0)
+
+
+def _guarded(solve_fn, problem, **kw):
+    """solve_fn(problem, **kw) -> info; an exception of any kind (library error, bad shapes, allocation failure) is
+    turned into a STATUS_ERROR record so that the worker -- and with it the rank -- always reaches the collective."""
+    try:
+        return dict(solve_fn(problem, **kw))
+    except Exception as e:
+        import sys
+        print("[batch] LP failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
+        return _error_info()
+
+
 def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, concurrent=False, start="reference",
               tol_gap=None):
     """Solve one LP (A, b, c) on `device` with the HIP path -> dict of statistics."""
@@ -56,12 +72,11 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
         _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device,
                                         regularize=regularize, concurrent=concurrent, start=start, tol_gap=tol_gap)
         info = dict(info)
-    except _lib.IpmError as e:
+    except Exception as e:          # every failure becomes a record: the rank must still reach the all-gather
         import sys
-        print("[batch] %d x %d LP failed: %s" % (A.shape[0], A.shape[1], e), file=sys.stderr, flush=True)
-        nan = float("nan")
-        info = dict(status=STATUS_INVALID_INPUT if e.code == _lib.ERR_INVALID_INPUT else STATUS_ERROR,
-                    iterations=0, objective=nan, rp=nan, rd=nan, gap=nan, pivots_fixed=0)
+        print("[batch] %d x %d LP failed: %s: %s" % (A.shape[0], A.shape[1], type(e).__name__, e), file=sys.stderr,
+              flush=True)
+        info = _error_info(STATUS_INVALID_INPUT if getattr(e, "code", None) == _lib.ERR_INVALID_INPUT else STATUS_ERROR)
     info["seconds"] = time.perf_counter() - t0
     return info
 
@@ -98,9 +113,10 @@ def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
         t0 = time.perf_counter()
         if workers > 1 and problems[i][0].shape[0] <= SMALL_ROWS:
             # handles that share the GPU must not poll on the device (IPM_FLAG_NO_DEVICE_POLLING, include/ipm_hip.h)
-            info = dict(_in_own_stream(solve_fn, problems[i], device, dict(kw, concurrent=True) if solve_fn is solve_one else kw))
+            info = _guarded(lambda p, **k: _in_own_stream(solve_fn, p, device, k), problems[i],
+                            **(dict(kw, concurrent=True) if solve_fn is solve_one else kw))
         else:
-            info = dict(solve_fn(problems[i], device=device, **kw))
+            info = _guarded(solve_fn, problems[i], device=device, **kw)
         info.setdefault("seconds", time.perf_counter() - t0)
         rec[row] = [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]),
                     float(info["rp"]), float(info["rd"]), float(info["gap"]), float(info["seconds"]),
@@ -144,13 +160,16 @@ def gather_records(local, shard_sizes, dist=None, device=None):
 _CALLS = 0          # run_batch() calls so far: names the shared work counter of a call (same sequence on every rank)
 
 
-def _rendezvous_store(dist):
-    """The process group's rendezvous key-value store (a TCP store on the master address): control plane only."""
-    try:
-        from torch.distributed import distributed_c10d as c10d
-        return c10d._get_default_store()
-    except Exception:
-        return None
+def make_store(rank, world, host=None, port=None, timeout_s=300):
+    """A TCP key-value store for the self-scheduling counter (public torch.distributed.TCPStore API; rank 0 hosts it).
+    Control plane only: one small round trip per LP.  The caller may hand the same store to init_process_group."""
+    import datetime
+    import os
+    import torch.distributed as tdist
+    host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    return tdist.TCPStore(host, port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s),
+                          wait_for_workers=True)
 
 
 def _solve_dynamic(problems, order, store, key, device, solve_fn, workers, **kw):
@@ -175,9 +194,10 @@ def _solve_dynamic(problems, order, store, key, device, solve_fn, workers, **kw)
             i = order[j]
             t0 = time.perf_counter()
             if workers > 1:
-                info = dict(_in_own_stream(solve_fn, problems[i], device, dict(kw, concurrent=True) if solve_fn is solve_one else kw))
+                info = _guarded(lambda p, **k: _in_own_stream(solve_fn, p, device, k), problems[i],
+                                **(dict(kw, concurrent=True) if solve_fn is solve_one else kw))
             else:
-                info = dict(solve_fn(problems[i], device=device, **kw))
+                info = _guarded(solve_fn, problems[i], device=device, **kw)
             info.setdefault("seconds", time.perf_counter() - t0)
             rec[i] = [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]),
                       float(info["rp"]), float(info["rd"]), float(info["gap"]), float(info["seconds"]),
@@ -209,12 +229,12 @@ def _gather_sparse(rec, dist, device=None):
 
 
 def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1,
-              schedule="static", **kw):
+              schedule="static", store=None, **kw):
     """Shard `problems` (list of (A, b, c)) over the ranks of `dist`, solve, gather statistics.
 
     schedule="static": deterministic LPT partition on the predicted cost, no scheduling traffic at all.
-    schedule="dynamic" (N > 1): the ranks pull LPs, most expensive first, from a counter on the process group's
-    rendezvous store (falls back to "static" when the store is not reachable).  Either way the only collective is
+    schedule="dynamic" (N > 1): the ranks pull LPs, most expensive first, from a counter on `store` (a
+    torch.distributed store shared by all ranks, e.g. make_store(); without one the schedule is "static").  Either way the only collective is
     ONE all-gather of the statistics records.  Returns (records sorted by id, this rank's wall seconds).  Without an
     initialised process group this is the single-GPU loop."""
     global _CALLS
@@ -223,7 +243,7 @@ def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, sol
     rank = dist.get_rank() if world > 1 else 0
     if costs is None:
         costs = [predicted_cost(p[0].shape[0], p[0].shape[1]) for p in problems]
-    store = _rendezvous_store(dist) if (world > 1 and schedule == "dynamic") else None
+    store = store if (world > 1 and schedule == "dynamic") else None
     t0 = time.perf_counter()
     if store is not None:
         order = sorted(range(len(problems)), key=lambda i: (-float(costs[i]), i))

@@ -92,7 +92,11 @@ void gemm_nt_f64_kernel(GemmNT g) {
             unsigned spins = 0;
             while (__hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 24)) {             // give up: no hang; the host reports the failure
+                ++spins;
+                // give up (no hang; the host rolls the call back and repeats it with stream events): after ~1 s of
+                // waiting, or at once when an earlier poll of this call already gave up
+                if (spins > (1u << 22) || ((spins & 1023u) == 1u && g.timeout &&
+                                           __hip_atomic_load(g.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     if (g.timeout) __hip_atomic_store(g.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -122,7 +126,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
             bid = xcd_remap(blockIdx.x, g.n_direct) + g.tile_offset;
         } else {
             int r = (int)blockIdx.x - g.n_direct;
-            bid = g.n_direct + r / g.split_p;
+            bid = g.tile_offset + g.n_direct + r / g.split_p;
             kbeg = (r % g.split_p) * g.chunk_stages;
             kend = min(kend, kbeg + g.chunk_stages);
             slab_out = g.slab + (size_t)r * (BM * BN);
@@ -272,7 +276,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmNT g) {
     if (g.done && *g.done) return;
-    const int tile = g.n_direct + blockIdx.y;
+    const int tile = g.tile_offset + g.n_direct + blockIdx.y;
     int ti, tj;
     if (g.tile_order) {
         int packed = g.tile_order[tile];

@@ -23,11 +23,19 @@
 #include "vector_ops.h"
 
 #include <algorithm>
+#include <atomic>
 #include <utility>
 
 using namespace ipm;
 
 static thread_local char g_err[512] = "";
+
+// Live handles per device.  The device-polled hand-offs of the Cholesky look-ahead are only safe while ONE handle
+// drives the GPU (its two streams then sit on hardware queues of their own); with more than one live handle on a
+// device every factorization uses stream events instead (enqueue_factor).  Counted at create / destroy.
+static const int MAX_DEVICES = 64;
+static std::atomic<int> g_live[MAX_DEVICES];
+static std::atomic<bool> g_attr_set[MAX_DEVICES];      // per-device function attributes (dynamic LDS of adat_sparse)
 
 struct ipm_handle {
     int device = 0;
@@ -48,6 +56,10 @@ struct ipm_handle {
     int bulk_variant = 0;                 // 1: BK=32 tiles for the bulk trailing update (measured slower: 2.38 vs 2.26 ms)
     int crit_variant = 1;                 // smaller tiles / deeper K steps for the two critical-path GEMMs
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
+    int last_gs = 1, n_counter_steps = 0, n_event_steps = 0, timeouts_recovered = 0;   // ipm_get_schedule
+    bool counted = false;                 // this handle is in g_live
+    double shift_rel = 0.0;               // Tikhonov shift in effect (opt.regularize, or 1e-14 switched on by ipm_solve)
+    int auto_reg = 0;                     // 1: the shift was switched on automatically
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
     int64_t m = 0, n = 0, mp = 0, np = 0;
     int nblk = 0, rc_chunks = 0, rows_per_chunk = 0, vblk = 0;
@@ -76,6 +88,8 @@ struct ipm_handle {
     double *d_rval = nullptr, *d_cval = nullptr;
     long long* stamp_buf = nullptr;       // diagnostic only (IPM_POTRF_STAMPS=1)
     Scalars* sc = nullptr;
+    IterRec* hist = nullptr;              // [HIST_CAP] per-iteration records (ring)
+    double* snap = nullptr;               // roll-back copy of (x, y, s) + Scalars (poll time-out / auto-regularize restart)
     int* fixed = nullptr;
     Scalars* h_sc = nullptr;          // pinned host mirror
     bool haveA = false, haveBC = false, haveState = false, predictor_valid = false;
@@ -117,7 +131,7 @@ static GemmNT gemm_defaults() {
 struct Layout {
     int64_t mp, np;
     int nblk, rc_chunks, rows_per_chunk, vblk;
-    size_t off_A, off_B, off_inv, off_nvec, off_mvec, off_atp, off_part, off_sc, off_fixed, off_slab, total;
+    size_t off_A, off_B, off_inv, off_nvec, off_mvec, off_atp, off_part, off_sc, off_fixed, off_hist, off_snap, off_slab, total;
     size_t off_rowptr, off_colind, off_rval, off_colptr, off_rowind, off_cval, off_order;
 };
 static const int N_NVEC = 11;   // x s c rc d v q dxa dsa dx ds
@@ -153,6 +167,8 @@ static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     L.off_part = take(sizeof(double) * P_NSLOT * MAXPART);
     L.off_sc = take(sizeof(Scalars));
     L.off_fixed = take(256);
+    L.off_hist = take(sizeof(IterRec) * HIST_CAP);
+    L.off_snap = take(sizeof(double) * (2 * L.np + L.mp) + sizeof(Scalars));
     L.off_slab = take(sizeof(double) * (size_t)kSlabTiles * 128 * 128);   // split-K partial tiles (64 MB)
     L.off_order = take(sizeof(int) * ((size_t)L.nblk * (L.nblk + 1) / 2));
     L.off_rowptr = take(sparse_nnz > 0 ? sizeof(int) * (m + 1) : 0);
@@ -206,7 +222,7 @@ __global__ void set_params_kernel(Scalars* sc, double e1, double e2, double e3, 
     sc->e1 = e1; sc->e2 = e2; sc->e3 = e3; sc->eta = eta;
     sc->max_iter = max_iter; sc->force = force;
     sc->done = 0; sc->status = 0;
-    if (reset) { sc->k = 0; sc->fixed = 0; }
+    if (reset) { sc->k = 0; sc->fixed = 0; sc->fixed_first = 0; sc->obj_last_finite = __builtin_nan(""); }
 }
 
 extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* opts, void* workspace,
@@ -224,6 +240,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (!(h->opt.eta > 0.0)) h->opt.eta = 0.91;
     if (!(h->opt.pivot_guard_big > 0.0)) h->opt.pivot_guard_big = 1e64;
     if (!(h->opt.regularize >= 0.0)) h->opt.regularize = 0.0;
+    h->shift_rel = h->opt.regularize;
     if (h->opt.sparse_nnz < 0) h->opt.sparse_nnz = 0;
     h->sparse = h->opt.sparse_nnz > 0;
     h->nnz_cap = h->opt.sparse_nnz;
@@ -269,6 +286,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->part = (double*)(base + L.off_part);
     h->sc = (Scalars*)(base + L.off_sc);
     h->fixed = (int*)(base + L.off_fixed);
+    h->hist = (IterRec*)(base + L.off_hist);
+    h->snap = (double*)(base + L.off_snap);
     h->slab = (double*)(base + L.off_slab);
     h->d_tile_order = (int*)(base + L.off_order);
     {   // lower tiles enumerated super-block by super-block (8 x 8 tiles): the ~64 workgroups an XCD runs
@@ -328,10 +347,15 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_crit[k], hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_bulk[k], hipEventDisableTiming));
     }
+    if (h->sparse && h->mp <= SP_LDS_MAX_MP && device < MAX_DEVICES && !g_attr_set[device].load(std::memory_order_acquire)) {
+        CREATE_TRY(hipFuncSetAttribute((const void*)adat_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8));
+        g_attr_set[device].store(true, std::memory_order_release);      // idempotent: a concurrent second call is harmless
+    }
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 5000, 0, 1);
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
+    if (device < MAX_DEVICES) { g_live[device].fetch_add(1, std::memory_order_acq_rel); h->counted = true; }
     *out = h;
     return IPM_OK;
 }
@@ -339,6 +363,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
 extern "C" int ipm_destroy(ipm_handle* h) {
     if (!h) return IPM_OK;
     (void)hipSetDevice(h->device);
+    if (h->counted) g_live[h->device].fetch_sub(1, std::memory_order_acq_rel);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk})
@@ -523,7 +548,7 @@ static VecArgs vec_args(ipm_handle* h) {
     a.atp = h->atp; a.x = h->x; a.y = h->y; a.s = h->s; a.b = h->b; a.c = h->c;
     a.rb = h->rb; a.rc = h->rc; a.d = h->d; a.v = h->v; a.q = h->q;
     a.dxa = h->dxa; a.dya = h->dya; a.dsa = h->dsa; a.dx = h->dx; a.dy = h->dy; a.ds = h->ds;
-    a.part = h->part; a.sc = h->sc;
+    a.part = h->part; a.sc = h->sc; a.hist = h->hist;
     return a;
 }
 
@@ -569,12 +594,7 @@ static int enqueue_residuals(ipm_handle* h) {
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
 static int enqueue_form(ipm_handle* h, const double* d) {
     if (h->sparse) {
-        if (h->mp <= SP_LDS_MAX_MP) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIP_TRY(h, hipFuncSetAttribute((const void*)adat_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8));
-                attr_set = true;
-            }
+        if (h->mp <= SP_LDS_MAX_MP) {          // dynamic-LDS attribute set per device in ipm_create
             hipLaunchKernelGGL(adat_sparse_kernel, dim3((unsigned)h->mp), dim3(256), (size_t)h->mp * sizeof(double), h->stream,
                                sparse_view(h), d, h->B, h->mp, (int)h->mp, &h->sc->done);
         } else {
@@ -623,7 +643,10 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         else if (h->nblk >= 48) gs = 3;
     }
     hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
-    const bool fs = la && h->flag_sync != 0;
+    // device-polled hand-offs only while this is the one live handle on the device (see g_live)
+    const bool alone = h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
+    const bool fs = la && h->flag_sync != 0 && alone;
+    h->last_gs = gs; h->n_counter_steps = 0; h->n_event_steps = 0;
     std::vector<unsigned> bulk_wgs(h->nblk, 0u);          // workgroups of the bulk update of each step
     if (la) {
         if (fs) HIP_TRY(h, hipMemsetAsync(h->d_bulk_done, 0, sizeof(unsigned) * 2 * (size_t)h->nblk, sm));
@@ -634,7 +657,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
         pd.inv = h->invD + (int64_t)k * NB * NB;
-        pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->opt.regularize;
+        pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
@@ -716,7 +739,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
                 ub.P = panel + (int64_t)NB * h->mp; ub.Q = panel;
                 ub.C = h->B + (int64_t)(k + 2) * NB * h->mp + (int64_t)(k + 1) * NB;
                 ub.M = rem - NB; ub.N = std::min(wn * NB, rem); ub.lower = 0;
-                if (fs) { bulk_wgs[k] = (unsigned)((ub.M / NB) * (ub.N / NB)); ub.signal = h->d_bulk_done + k; }
+                if (fs) { bulk_wgs[k] = (unsigned)((ub.M / NB) * (ub.N / NB)); ub.signal = h->d_bulk_done + k; ++h->n_counter_steps; }
+                else ++h->n_event_steps;
                 HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb)));
                 HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
                 continue;
@@ -727,7 +751,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
             if (fs && ub_wgs <= 1024) {
                 bulk_wgs[k] = (unsigned)ub_wgs;
                 ub.signal = h->d_bulk_done + k;
-            }
+                ++h->n_counter_steps;
+            } else ++h->n_event_steps;
             if (h->bulk_variant == 1) HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
             else HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
         }
@@ -904,20 +929,64 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     return IPM_OK;
 }
 
-static int read_scalars(ipm_handle* h) {
+// Host copy of the scalar record (one sync).  *timed_out (optional) receives the poll time-out word of the
+// device-side hand-offs and the word is cleared; without it a time-out is an error.
+static int read_scalars(ipm_handle* h, bool* timed_out = nullptr) {
     unsigned tmo = 0;
+    unsigned* word = h->d_flags + 2 * (size_t)h->nblk;
     HIP_TRY(h, hipMemcpyAsync(h->h_sc, h->sc, sizeof(Scalars), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(&tmo, h->d_flags + 2 * (size_t)h->nblk, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&tmo, word, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (tmo) return fail(h, IPM_ERR_HIP, "a device-side hand-off poll timed out (Cholesky look-ahead counters / persistent solve)");
+    if (tmo) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream2));               // the bulk stream may still be draining
+        HIP_TRY(h, hipMemsetAsync(word, 0, sizeof(unsigned), h->stream));
+        if (!timed_out) return fail(h, IPM_ERR_HIP, "a device-side hand-off poll timed out (persistent solve)");
+    }
+    if (timed_out) *timed_out = tmo != 0;
     return IPM_OK;
 }
+
+// A poll time-out means a consumer gave up waiting and computed on stale tiles: the results of the call are
+// garbage but nothing hung.  Policy: never surface it -- switch this handle to stream events for good, undo the
+// call's effect on the iterate (callers restore their snapshot) and run it again.
+static void poll_fallback(ipm_handle* h) {
+    h->flag_sync = 0;
+    ++h->timeouts_recovered;
+}
+
+// (x, y, s, Scalars) <-> roll-back buffer, one launch
+__global__ __launch_bounds__(256) void snapshot_kernel(double* x, double* y, double* s, Scalars* sc, double* snap, int np,
+                                                       int mp, int restore) {
+    const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    double *sx = snap, *ss = snap + np, *sy = snap + 2 * (size_t)np;
+    Scalars* ssc = (Scalars*)(snap + 2 * (size_t)np + mp);
+    if (restore) {
+        for (int j = gid; j < np; j += gsz) { x[j] = sx[j]; s[j] = ss[j]; }
+        for (int i = gid; i < mp; i += gsz) y[i] = sy[i];
+        if (gid == 0) *sc = *ssc;
+    } else {
+        for (int j = gid; j < np; j += gsz) { sx[j] = x[j]; ss[j] = s[j]; }
+        for (int i = gid; i < mp; i += gsz) sy[i] = y[i];
+        if (gid == 0) *ssc = *sc;
+    }
+}
+static int enqueue_snapshot(ipm_handle* h, int restore) {
+    const int64_t mx = h->np > h->mp ? h->np : h->mp;
+    const unsigned grid = (unsigned)std::min<int64_t>((mx + 255) / 256, 256);
+    hipLaunchKernelGGL(snapshot_kernel, dim3(grid), dim3(256), 0, h->stream, h->x, h->y, h->s, h->sc, h->snap, (int)h->np,
+                       (int)h->mp, restore);
+    HIP_TRY(h, hipGetLastError());
+    return IPM_OK;
+}
+// can the next factorization time out at all?  (mirrors the `fs` rule of enqueue_factor)
+static bool may_poll(const ipm_handle* h) { return h->lookahead != 0 && h->nblk > 2 && h->flag_sync != 0; }
 
 static void fill_stats(ipm_handle* h, ipm_stats* st, double ms) {
     if (!st) return;
     const Scalars& s = *h->h_sc;
     memset(st, 0, sizeof *st);
-    st->status = s.status; st->iterations = s.k; st->pivots_fixed = s.fixed;
+    st->status = s.status; st->iterations = s.k; st->pivots_fixed = s.fixed; st->auto_regularized = h->auto_reg;
+    st->objective_last_finite = s.obj_last_finite;
     st->objective = s.obj; st->rp_norm = s.rb_norm; st->rd_norm = s.rc_norm; st->gap = s.gap;
     st->b_norm = s.b_norm; st->c_norm = s.c_norm; st->mu = s.mu; st->mu_aff = s.mu_aff; st->sigma = s.sigma;
     st->alpha_aff_p = s.alpha_aff_p; st->alpha_aff_d = s.alpha_aff_d; st->alpha_p = s.alpha_p; st->alpha_d = s.alpha_d;
@@ -936,14 +1005,21 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
     if (rc) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     if (!corrector) {
-        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
-        if ((rc = enqueue_residuals(h))) return rc;
-        if ((rc = enqueue_form(h, h->d))) return rc;
-        if ((rc = enqueue_factor(h, true))) return rc;
-        if ((rc = enqueue_group_inverses(h))) return rc;
-        if ((rc = enqueue_predictor(h, nullptr))) return rc;
-        VecArgs a = vec_args(h);
-        hipLaunchKernelGGL(mu_aff_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);   // alpha_aff for stats
+        for (int attempt = 0;; ++attempt) {                 // second pass only after a recovered poll time-out
+            hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
+            if ((rc = enqueue_residuals(h))) return rc;
+            if ((rc = enqueue_form(h, h->d))) return rc;
+            if ((rc = enqueue_factor(h, true))) return rc;
+            if ((rc = enqueue_group_inverses(h))) return rc;
+            if ((rc = enqueue_predictor(h, nullptr))) return rc;
+            VecArgs a = vec_args(h);
+            hipLaunchKernelGGL(mu_aff_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);   // alpha_aff for stats
+            bool tmo = false;
+            if ((rc = read_scalars(h, &tmo))) return rc;
+            if (!tmo) break;
+            if (attempt) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
+            poll_fallback(h);
+        }
         h->predictor_valid = true;
         if (dx) HIP_TRY(h, hipMemcpyAsync(dx, h->dxa, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
         if (dy) HIP_TRY(h, hipMemcpyAsync(dy, h->dya, sizeof(double) * h->m, hipMemcpyDeviceToHost, h->stream));
@@ -958,7 +1034,8 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
         if (dy) HIP_TRY(h, hipMemcpyAsync(dy, h->dy, sizeof(double) * h->m, hipMemcpyDeviceToHost, h->stream));
         if (ds) HIP_TRY(h, hipMemcpyAsync(ds, h->ds, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
     }
-    if ((rc = read_scalars(h))) return rc;
+    if (corrector && (rc = read_scalars(h))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     fill_stats(h, stats, 0.0);
     return IPM_OK;
 }
@@ -988,17 +1065,32 @@ extern "C" int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats) {
     HIP_TRY(h, hipSetDevice(h->device));
     h->predictor_valid = false;
     std::vector<hipEvent_t> evs;
+    struct EvGuard {                                   // destroyed on every return path
+        std::vector<hipEvent_t>& v;
+        ~EvGuard() { for (auto& e : v) if (e) (void)hipEventDestroy(e); }
+    } guard{evs};
     if (h->profiling) {
-        evs.resize((size_t)EV_PER_IT * n_steps);
+        evs.assign((size_t)EV_PER_IT * n_steps, nullptr);
         for (auto& e : evs) HIP_TRY(h, hipEventCreate(&e));
     }
-    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
-    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    for (int it = 0; it < n_steps; ++it)
-        if ((rc = enqueue_iteration(h, h->profiling ? &evs[(size_t)it * EV_PER_IT] : nullptr))) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    if ((rc = read_scalars(h))) return rc;
     float ms = 0.f;
+    for (int attempt = 0;; ++attempt) {
+        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
+        const bool guard_poll = may_poll(h) && n_steps > 0;
+        if (guard_poll && (rc = enqueue_snapshot(h, 0))) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        for (int it = 0; it < n_steps; ++it)
+            if ((rc = enqueue_iteration(h, h->profiling ? &evs[(size_t)it * EV_PER_IT] : nullptr))) return rc;
+        // residuals + stop test of the state just reached: the statistics describe what ipm_get_state returns
+        if ((rc = enqueue_residuals(h))) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        bool tmo = false;
+        if ((rc = read_scalars(h, &tmo))) return rc;
+        if (!tmo) break;
+        if (attempt || !guard_poll) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
+        poll_fallback(h);
+        if ((rc = enqueue_snapshot(h, 1))) return rc;
+    }
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (h->profiling && n_steps > 0) {
         double ph[4] = {0, 0, 0, 0};
@@ -1016,7 +1108,6 @@ extern "C" int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats) {
             ph[3] += total - f12 - f23 - s1 - s2;
         }
         for (int i = 0; i < 4; ++i) h->phase_ms[i] = ph[i] / n_steps;
-        for (auto& e : evs) (void)hipEventDestroy(e);
     }
     fill_stats(h, stats, ms);
     return IPM_OK;
@@ -1028,13 +1119,37 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     if (max_iter < 0) return fail(h, IPM_ERR_INVALID_ARG, "max_iter < 0");
     HIP_TRY(h, hipSetDevice(h->device));
     h->predictor_valid = false;
+    if (h->auto_reg) { h->auto_reg = 0; h->shift_rel = h->opt.regularize; }      // decided per solve
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, tol_p, tol_d, tol_gap, h->opt.eta, max_iter, 0, 1);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     const int chunk = h->opt.check_every;
+    const bool may_auto = h->opt.regularize == 0.0 && !(h->opt.flags & IPM_FLAG_NO_AUTO_REGULARIZE);
+    bool first = true;
+    int recovered = 0;
     for (;;) {
+        // roll-back point: the first chunk (auto-regularize restart) and every chunk that can hit a poll time-out
+        const bool snap = first || may_poll(h);
+        if (snap && (rc = enqueue_snapshot(h, 0))) return rc;
         for (int i = 0; i < chunk; ++i)
             if ((rc = enqueue_iteration(h, nullptr))) return rc;
-        if ((rc = read_scalars(h))) return rc;
+        bool tmo = false;
+        if ((rc = read_scalars(h, &tmo))) return rc;
+        if (tmo) {
+            if (!snap || ++recovered > 2) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
+            poll_fallback(h);
+            if ((rc = enqueue_snapshot(h, 1))) return rc;
+            continue;                                          // same chunk again, with stream events
+        }
+        if (first && may_auto && h->h_sc->k > 0 && (double)h->h_sc->fixed_first > 0.05 * (double)h->m) {
+            // A has > 5 % dependent rows (QAP family): the guard alone stalls the loop.  Restart
+            // this solve from its start state with the 1e-14 Tikhonov shift.  No other Netlib file crosses 2.7 %, so
+            // every solve that does not take this branch is bit-identical to one with the flag off.
+            h->shift_rel = 1e-14; h->auto_reg = 1;
+            if ((rc = enqueue_snapshot(h, 1))) return rc;
+            first = false;
+            continue;
+        }
+        first = false;
         if (h->h_sc->done) break;
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -1042,6 +1157,34 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     fill_stats(h, stats, ms);
+    return IPM_OK;
+}
+
+extern "C" int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32_t* count) {
+    if (!h || !count || capacity < 0 || (capacity > 0 && !out)) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_history: bad arguments");
+    static_assert(sizeof(ipm_iter_record) == sizeof(IterRec), "history record layout");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int k = 0;
+    HIP_TRY(h, hipMemcpyAsync(&k, &h->sc->k, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int nrec = std::min(std::min(k, HIST_CAP), (int)capacity);
+    if (nrec > 0) {
+        std::vector<IterRec> ring(HIST_CAP);
+        HIP_TRY(h, hipMemcpyAsync(ring.data(), h->hist, sizeof(IterRec) * HIST_CAP, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < nrec; ++i) memcpy(&out[i], &ring[(size_t)(k - nrec + i) % HIST_CAP], sizeof(IterRec));
+    }
+    *count = nrec;
+    return IPM_OK;
+}
+
+extern "C" int ipm_get_schedule(ipm_handle* h, int32_t out[10]) {
+    if (!h || !out) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_schedule: bad arguments");
+    const int live = h->device < MAX_DEVICES ? g_live[h->device].load(std::memory_order_acquire) : 1;
+    out[0] = h->nblk; out[1] = h->last_gs; out[2] = h->grouped_trsv;
+    out[3] = (may_poll(h) && live <= 1) ? 1 : 0;
+    out[4] = h->n_counter_steps; out[5] = h->n_event_steps; out[6] = h->use_env ? 1 : 0; out[7] = live;
+    out[8] = h->timeouts_recovered; out[9] = 0;
     return IPM_OK;
 }
 
@@ -1071,22 +1214,29 @@ extern "C" int ipm_normal_solve(ipm_handle* h, const double* d, const double* rh
     if (!h->haveA) return fail(h, IPM_ERR_STATE, "ipm_normal_solve: A not set");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc;
-    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 1);
-    if (!reuse_factor) {
-        if (d) {
-            HIP_TRY(h, hipMemcpyAsync(h->d, d, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
-        } else {
-            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->d, (int)h->n, 1.0);
+    for (int attempt = 0;; ++attempt) {                     // second pass only after a recovered poll time-out
+        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 1);
+        if (!reuse_factor) {
+            if (d) {
+                HIP_TRY(h, hipMemcpyAsync(h->d, d, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+            } else {
+                hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->d, (int)h->n, 1.0);
+            }
+            if ((rc = enqueue_form(h, h->d))) return rc;
+            if ((rc = enqueue_factor(h, true))) return rc;
+            if ((rc = enqueue_group_inverses(h))) return rc;
         }
-        if ((rc = enqueue_form(h, h->d))) return rc;
-        if ((rc = enqueue_factor(h, true))) return rc;
-        if ((rc = enqueue_group_inverses(h))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->t1, 0, sizeof(double) * h->mp, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->t1, rhs, sizeof(double) * h->m, hipMemcpyHostToDevice, h->stream));
+        if ((rc = enqueue_potrs(h, h->t1, h->dy))) return rc;
+        bool tmo = false;
+        if ((rc = read_scalars(h, &tmo))) return rc;
+        if (!tmo) break;
+        if (attempt || reuse_factor) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
+        poll_fallback(h);
     }
-    HIP_TRY(h, hipMemsetAsync(h->t1, 0, sizeof(double) * h->mp, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->t1, rhs, sizeof(double) * h->m, hipMemcpyHostToDevice, h->stream));
-    if ((rc = enqueue_potrs(h, h->t1, h->dy))) return rc;
     HIP_TRY(h, hipMemcpyAsync(z, h->dy, sizeof(double) * h->m, hipMemcpyDeviceToHost, h->stream));
-    if ((rc = read_scalars(h))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (pivots_fixed) *pivots_fixed = h->h_sc->fixed;
     h->predictor_valid = false;
     return IPM_OK;
@@ -1112,19 +1262,28 @@ extern "C" int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, con
         if (i < m) memcpy(&img[(size_t)i * mp], B + i * ldb, sizeof(double) * m);
         else img[(size_t)i * mp + i] = 1.0;
     }
-    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 1);
-    HIP_TRY(h, hipMemcpyAsync(h->B, img.data(), sizeof(double) * mp * mp, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->t1, 0, sizeof(double) * mp, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->t1, rhs, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
     const bool saved_env = h->use_env;
     h->use_env = false;                                   // an arbitrary dense B: no structure to exploit
-    int rc = enqueue_factor(h);
-    if (!rc) rc = enqueue_group_inverses(h);
-    if (!rc) rc = enqueue_potrs(h, h->t1, h->dy);
+    int rc = IPM_OK;
+    for (int attempt = 0;; ++attempt) {                   // second pass only after a recovered poll time-out
+        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 1);
+        hipError_t e = hipMemcpyAsync(h->B, img.data(), sizeof(double) * mp * mp, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->t1, 0, sizeof(double) * mp, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->t1, rhs, sizeof(double) * m, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) { h->use_env = saved_env; return fail(h, IPM_ERR_HIP, "ipm_solve_linear: upload failed: %s", hipGetErrorString(e)); }
+        rc = enqueue_factor(h);
+        if (!rc) rc = enqueue_group_inverses(h);
+        if (!rc) rc = enqueue_potrs(h, h->t1, h->dy);
+        bool tmo = false;
+        if (!rc) rc = read_scalars(h, &tmo);
+        if (rc || !tmo) break;
+        if (attempt) { rc = fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events"); break; }
+        poll_fallback(h);
+    }
     h->use_env = saved_env;
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(z, h->dy, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
-    if ((rc = read_scalars(h))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (pivots_fixed) *pivots_fixed = h->h_sc->fixed;
     h->predictor_valid = false;
     return IPM_OK;

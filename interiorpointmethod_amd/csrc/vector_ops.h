@@ -32,8 +32,16 @@ struct Scalars {
     double alpha_aff_p, alpha_aff_d, alpha_p, alpha_d;
     double maxdiag;
     double e1, e2, e3, eta;
-    int done, status, k, max_iter, fixed, force, pad0, pad1;
+    double obj_last_finite;      // last finite c^T x seen by the stop test (main.py:1227-1233 returns it on NaN)
+    int done, status, k, max_iter, fixed, force, fixed_first, pad1;   // fixed_first: guarded pivots of the first factorization
 };
+
+// per-iteration record (include/ipm_hip.h: ipm_iter_record), written by update_kernel into a ring
+struct IterRec {
+    int k, fixed;
+    double obj, rb, rc, gap, mu, sigma, aap, aad, ap, ad;
+};
+constexpr int HIST_CAP = 1024;
 
 // partial-sum slots (each MAXPART doubles)
 enum { P_RC2 = 0, P_XS, P_CX, P_RB2, P_MINP_AFF, P_MIND_AFF, P_MUAFF, P_MINP, P_MIND, P_NSLOT };
@@ -128,6 +136,7 @@ struct VecArgs {
     double *dxa, *dya, *dsa, *dx, *dy, *ds;
     double* part;                  // [P_NSLOT][MAXPART]
     Scalars* sc;
+    IterRec* hist;                 // [HIST_CAP] ring of per-iteration records
 };
 
 __device__ __forceinline__ double col_sum(const double* atp, int rc_chunks, int np, int j) {
@@ -173,7 +182,9 @@ __global__ void stop_test_kernel(VecArgs a) {
     double rc = sqrt(sum_partials(a.part, P_RC2, a.nblk));
     double gap = sum_partials(a.part, P_XS, a.nblk);
     sc->rb_norm = rb; sc->rc_norm = rc; sc->gap = gap;
-    sc->obj = sum_partials(a.part, P_CX, a.nblk);
+    const double obj = sum_partials(a.part, P_CX, a.nblk);
+    sc->obj = obj;
+    if (fabs(obj) < 1.7e308) sc->obj_last_finite = obj;          // false for NaN and Inf
     sc->mu = gap / (double)a.n;
     bool cont = (sc->e1 * (1.0 + sc->b_norm) < rb) || (sc->e2 * (1.0 + sc->c_norm) < rc) || (sc->e3 < gap);
     if (sc->force) return;
@@ -260,7 +271,16 @@ __global__ __launch_bounds__(VBLK) void update_kernel(VecArgs a) {
         a.s[j] += ad * a.ds[j];
     }
     for (int i = gid; i < a.m; i += gsz) a.y[i] += ad * a.dy[i];
-    if (gid == 0) { a.sc->alpha_p = ap; a.sc->alpha_d = ad; a.sc->k += 1; }
+    if (gid == 0) {
+        Scalars* sc = a.sc;
+        const int k = sc->k;
+        if (k == 0) sc->fixed_first = sc->fixed;
+        IterRec r;
+        r.k = k; r.fixed = sc->fixed; r.obj = sc->obj; r.rb = sc->rb_norm; r.rc = sc->rc_norm; r.gap = sc->gap;
+        r.mu = sc->mu; r.sigma = sc->sigma; r.aap = sc->alpha_aff_p; r.aad = sc->alpha_aff_d; r.ap = ap; r.ad = ad;
+        a.hist[k % HIST_CAP] = r;
+        sc->alpha_p = ap; sc->alpha_d = ad; sc->k = k + 1;
+    }
 }
 
 // out[i] = value for i < n (fill)

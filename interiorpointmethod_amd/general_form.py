@@ -141,7 +141,10 @@ def new_interior_sparse(c, Aeq=None, beq=None, Aineq=None, bineq=None, lb=None, 
     A, b, cs, offset = standard_form(c, Aeq=Aeq, beq=beq, Aineq=Aineq, bineq=bineq, lb=lb, ub=ub)
     _, _, _, info = _solver.solve_with_info(A, b, cs, tol=tol, tol_gap=1e-6, max_iter=999, y0=1.0, device=device,
                                             start=start)            # start="mehrotra": optional, not the reference's
-    obj = info["objective"] + offset
+    obj = info["objective"]
+    if info["status"] == 3:                      # NaN iterate: the reference returns the last finite objective it saw
+        obj = info["objective_last_finite"]      # (main.py:1227-1233)
+    obj = obj + offset
     return (obj, info) if return_info else obj
 
 

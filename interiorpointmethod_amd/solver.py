@@ -78,7 +78,8 @@ class IpmSolver:
     """One LP bound to one GPU: owns a libipm_hip handle whose workspace is a torch tensor."""
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
-                 check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto", concurrent=False):
+                 check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto", concurrent=False,
+                 auto_regularize=True):
         lib = _lib.load()
         self._lib = lib
         self._h = None
@@ -111,7 +112,10 @@ class IpmSolver:
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
         opts.check_every = int(check_every)
         opts.regularize = float(regularize)
-        opts.flags = _lib.FLAG_NO_DEVICE_POLLING if concurrent else 0     # several handles at once on one GPU
+        # concurrent=True forces stream events from the start; without it the library still protects itself (it counts
+        # the live handles per device and falls back to events, include/ipm_hip.h)
+        opts.flags = (_lib.FLAG_NO_DEVICE_POLLING if concurrent else 0) | \
+                     (0 if auto_regularize else _lib.FLAG_NO_AUTO_REGULARIZE)
         nbytes = C.c_size_t(0)
         self.sparse = _sp is not None and _sp.issparse(A)
         if self.sparse:                      # A stays sparse on the device (CSR + CSC, sparse formation of B)
@@ -213,6 +217,23 @@ class IpmSolver:
         self.stats = st.as_dict()
         return self.stats
 
+    def history(self):
+        """Per-iteration records of the last solve()/iterate() (oldest first; the most recent 1024): list of dicts
+        with k, objective, rp_norm, rd_norm, gap, mu, sigma, alpha_aff_p/d, alpha_p/d, pivots_fixed -- the line the
+        reference prints per iteration (main.py:808-809, :1186)."""
+        buf = (_lib.IterRecord * _lib.HISTORY_CAPACITY)()
+        n = C.c_int32(0)
+        self._check(self._lib.ipm_get_history(self._h, buf, _lib.HISTORY_CAPACITY, C.byref(n)))
+        return [{k: getattr(buf[i], k) for k, _ in _lib.IterRecord._fields_} for i in range(n.value)]
+
+    def schedule(self):
+        """How the handle runs its factorization (ipm_get_schedule): dict for tests and diagnostics."""
+        out = (C.c_int32 * 10)()
+        self._check(self._lib.ipm_get_schedule(self._h, out))
+        keys = ("blocks", "group_steps", "grouped_trsv", "device_polling", "counter_steps", "event_steps", "envelope",
+                "live_handles", "timeouts_recovered", "fused_small")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def set_profiling(self, level=2):
         """0 off, 1 time the A D^2 A^T kernel only, 2 all phases (True == 2 for old callers)."""
         level = 2 if level is True else (0 if level is False else int(level))
@@ -298,9 +319,13 @@ def last_info():
     return _last_info
 
 
-def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=None, start="reference", **opts):
+def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=None, start="reference",
+                    history=False, **opts):
     """solve() plus the statistics record (iterations, status, objective, rp, rd, gap, ...).
-    start="reference": x = s = 1, y = y0 as the reference does; start="mehrotra": IpmSolver.mehrotra_start()."""
+    start="reference": x = s = 1, y = y0 as the reference does; start="mehrotra": IpmSolver.mehrotra_start().
+    history=True adds info["history"], the per-iteration records (IpmSolver.history()).  An LP whose A has more
+    than 5 % dependent rows (the QAP family) is solved with the 1e-14 Tikhonov shift, switched on by the library
+    after the first factorization (info["auto_regularized"] == 1; auto_regularize=False keeps it off)."""
     global _last_info
     if start == "mehrotra" and not opts.get("regularize") and os.environ.get("IPM_AUTO_REGULARIZE", "1") != "0":
         # the least-squares start factors A A^T: guarded pivots there are dependent rows of A.  Where they are a
@@ -321,6 +346,8 @@ def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=
         sv.solve(tol=tol, max_iter=max_iter, tol_gap=tol_gap)
         x, y, s = sv.get_state()
         info = _info(sv)
+        if history:
+            info["history"] = sv.history()
     _last_info = info
     return x, y, s, info
 

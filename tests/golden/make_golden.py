@@ -3,7 +3,7 @@
 
 Run in the build container only (needs /root/reference, read-only):
 
-    python3 tests/golden/make_golden.py [--only kat|e2e|dense|qap15|netlib] [--jobs 6]
+    python3 tests/golden/make_golden.py [--only kat|e2e|dense|dense_large|qap15|netlib] [--jobs 6]
 
 The reference's Python never travels to the GPU box; only the small .npz files
 written here do.  Every number stored in an ``expected_*`` / ``ref_*`` key is
@@ -207,6 +207,42 @@ def make_dense(rm):
         print("dense %-12s it=%3d obj=%.13e" % (nm, k, store["objective"]), flush=True)
 
 
+def make_dense_large(rm, sizes=((1024, 2048), (4096, 8192))):
+    """Reference-verbatim dense solves above 512 x 1024 (the sizes where the HIP path's grouped triangular solves
+    and, at 4096 x 8192, the headline configuration run).  A itself is NOT stored (268 MB at 4096 x 8192: it is
+    regenerated from the seed by the same generator); stored are the reference's final (x, y, s), objective,
+    iteration count, residuals, the first-step scalars and the objective after every iteration.  4096 x 8192 takes
+    ~45-60 minutes (two LAPACK gesv of a 20480^2 matrix per iteration, main.py:185-244) and ~10 GB."""
+    tol = 1e-8
+    for (m, n) in sizes:
+        A, b, c = synthetic_lp(m, n)
+        x, y, s = rm.initial_vector(A)                            # main.py:287-302 (y=0)
+        k = 0
+        store = dict(b=b, c=c, shape=np.array(A.shape), tol=tol, seed=0)
+        traj = []
+        t0 = time.time()
+        with _quiet():
+            while rm.check_optimality(A, b, c, x, y, s, tol, tol, tol) and k < 50000:
+                st = ref_step_dense(rm, A, b, c, x, y, s)
+                if k == 0:
+                    for key, val in st.items():
+                        store["k0_" + key] = val
+                x, y, s = st["xn"], st["yn"], st["sn"]
+                k += 1
+                traj.append(float(np.sum(x * c)))
+                print("dense_large %dx%d k=%d obj=%.13e  %.0fs" % (m, n, k, traj[-1], time.time() - t0),
+                      file=sys.stderr, flush=True)
+        store.update(iterations=k, objective=float(np.sum(x * c)), x=x, y=y, s=s,
+                     objective_after_iteration=np.array(traj),
+                     gap=float((x.T @ s)[0, 0]),
+                     rp=float(np.linalg.norm(A @ x - b) / (1 + np.linalg.norm(b))),
+                     rd=float(np.linalg.norm(A.T @ y + s - c) / (1 + np.linalg.norm(c))),
+                     ref_seconds=time.time() - t0)
+        np.savez_compressed(os.path.join(HERE, "dense_syn_%dx%d.npz" % (m, n)), **store)
+        print("dense %-12s it=%3d obj=%.13e  %.0fs" % ("syn_%dx%d" % (m, n), k, store["objective"],
+                                                      store["ref_seconds"]), flush=True)
+
+
 # ---------------------------------------------------------------- 4. QAP15 direction KAT
 def make_qap15(rm, rsi):
     A, b, c, cTlb = load_f64(rsi, "QAP15")
@@ -269,6 +305,9 @@ if __name__ == "__main__":
             make_kat(rm, rsi)
         if args.only in ("all", "dense"):
             make_dense(rm)
+        if args.only == "dense_large":          # not part of "all": ~1 hour
+            make_dense_large(rm, [tuple(int(v) for v in t.split("x")) for t in args.names.split(",") if t]
+                             or ((1024, 2048), (4096, 8192)))
         if args.only in ("all", "netlib"):
             make_netlib(rsi)
         if args.only in ("all", "qap15"):

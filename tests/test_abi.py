@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(built_lib):
 
 def test_abi_version_and_host_only_calls(built_lib):
     lib = ipm.load_library()
-    assert lib.ipm_abi_version() == 1
+    assert lib.ipm_abi_version() == _lib.ABI_VERSION == 2
     opts = _lib.Options()
     lib.ipm_default_options(C.byref(opts))
     assert opts.eta == 0.91 and opts.pivot_guard_big == 1e64 and opts.check_every >= 1   # main.py:607
@@ -44,7 +44,8 @@ def test_abi_version_and_host_only_calls(built_lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Options) == 3 * 8 + 2 * 4 + 8 + 8
-    assert C.sizeof(_lib.Stats) == 4 * 4 + 14 * 8
+    assert C.sizeof(_lib.Stats) == 4 * 4 + 15 * 8
+    assert C.sizeof(_lib.IterRecord) == 2 * 4 + 10 * 8
 
 
 def test_no_cpu_fallback_without_device(built_lib):

@@ -41,19 +41,53 @@ def test_single_process_batch():
     assert s["total_iterations"] == sum(2 * m + 1 for m in (4, 9, 2, 7, 6))
 
 
-def _worker(rank, world, port, q, schedule="static", workers=1):
+def _raising_solve(problem, device=0, **kw):
+    """One LP of the batch fails with something that is NOT a library error (bad shapes, OOM, ...)."""
+    if problem[0].shape[0] == 7:
+        raise ValueError("b has length 3, expected 7")
+    return _fake_solve(problem, device=device, **kw)
+
+
+def _worker(rank, world, port, q, schedule="static", workers=1, solve_fn=_fake_solve):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the counter of the self-scheduling mode lives on an explicit TCPStore (public API), shared with the group
+    store = batch.make_store(rank, world, host="127.0.0.1", port=port)
+    dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
     try:
         probs = [(np.zeros((m, m + 1)), None, None) for m in (4, 9, 2, 7, 6, 11, 3)]
-        rec, secs = batch.run_batch(probs, dist=dist, solve_fn=_fake_solve, schedule=schedule, workers=workers)
-        rec2, _ = batch.run_batch(probs, dist=dist, solve_fn=_fake_solve, schedule=schedule, workers=workers)   # a second call: fresh counter
-        assert np.array_equal(rec[:, :7], rec2[:, :7])
+        rec, secs = batch.run_batch(probs, dist=dist, solve_fn=solve_fn, schedule=schedule, workers=workers, store=store)
+        rec2, _ = batch.run_batch(probs, dist=dist, solve_fn=solve_fn, schedule=schedule, workers=workers, store=store)   # a second call: fresh counter
+        assert np.array_equal(rec[:, :3], rec2[:, :3])
         q.put((rank, rec))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("schedule,workers", [("static", 1), ("dynamic", 2)])
+def test_two_rank_gloo_one_lp_raises(schedule, workers):
+    """An exception inside one solve must not keep its rank from the all-gather (the peers would block in the
+    collective until the process-group time-out): it becomes a STATUS_ERROR record, every other LP is solved."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, schedule, workers, _raising_solve)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        rec = got[r]
+        assert list(rec[:, 0]) == list(range(7))
+        assert rec[3, 1] == batch.STATUS_ERROR and np.isnan(rec[3, 3])
+        assert np.all(rec[[0, 1, 2, 4, 5, 6], 1] > 0)
+    assert batch.summarize(got[0])["errors"] == 1
 
 
 @pytest.mark.parametrize("schedule,workers", [("dynamic", 1), ("dynamic", 2)])

@@ -159,13 +159,16 @@ def load_netlib(which, max_m=1 << 30):
     import numpy as np
     from scipy import sparse
     from interiorpointmethod_amd.matio import load_npz_problem
-    from interiorpointmethod_amd.workloads import flops_per_iteration
+    from interiorpointmethod_amd.solver import factor_flops
     names, probs, flops = [], [], []
 
     def add(nm, A, b, c):
+        # flops of one iteration as the device runs it: sparse contraction sum_j nnz_j^2, the blocked Cholesky inside
+        # the tile envelope (m^3/3 when there is none), 4 m^2 for the four triangular sweeps, 12 nnz for the six SpMVs
         A = sparse.csc_matrix(A)
         names.append(nm); probs.append((A, b, c))
-        flops.append(flops_per_iteration(A.shape[0], A.shape[1], float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2))))
+        m = A.shape[0]
+        flops.append(float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2)) + factor_flops(A) + 4.0 * m * m + 12.0 * A.nnz)
 
     if which == "general":
         from interiorpointmethod_amd import general_form as G
@@ -194,10 +197,11 @@ def load_netlib(which, max_m=1 << 30):
 
 
 def netlib_roofline(names, probs, flops, rec, elapsed, world):
-    """Roofline view of a batched run.  Algorithmic flops of an LP = iterations x (sum_j nnz(A[:,j])^2 + m^3/3 + 4m^2
-    + 12 nnz-ish terms) (SURVEY 8d with the sparse contraction count); the suite is NOT flop bound -- every iteration
-    is a chain of dependent launches (measured cost model 0.1 ms + 0.11 ms per 128-row block, batch.predicted_cost) --
-    so the latency model's prediction is printed beside the MFMA fraction."""
+    """Roofline view of a batched run.  Algorithmic flops of an LP = iterations x (sum_j nnz(A[:,j])^2 + Cholesky + 4 m^2
+    + 12 nnz) (SURVEY 8d with the sparse contraction count; the Cholesky term is m^3/3, or the flops inside the tile
+    envelope where the device exploits it -- solver.factor_flops).  The suite is NOT flop bound: every iteration is a
+    chain of dependent launches (measured cost model 0.1 ms + 0.11 ms per 128-row block, batch.predicted_cost), so
+    the latency model's prediction is printed beside the MFMA fraction."""
     import numpy as np
     its = rec[:, 2]
     total = float(np.sum(its * np.array(flops)))
@@ -207,8 +211,9 @@ def netlib_roofline(names, probs, flops, rec, elapsed, world):
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS * max(world, 1), "unit": "TFLOP/s",
             "frac": ach / (PEAK_FP64_MFMA_TFLOPS * max(world, 1)), "traffic": None,
             "flops_total": total, "iterations_total": int(its.sum()),
-            "note": "sum over LPs of iterations x (sum_j nnz_j^2 + m^3/3 + 4 m^2 + 12 m n) / wall / (78.6 TFLOP/s x GPUs); "
-                    "the suite is bound by the per-iteration launch chain, not by flops",
+            "note": "sum over LPs of iterations x (sum_j nnz_j^2 + Cholesky flops [m^3/3, or inside the tile envelope where "
+                    "the factorization skips structural zeros] + 4 m^2 + 12 nnz) / wall / (78.6 TFLOP/s x GPUs); the suite is "
+                    "bound by the per-iteration launch chain, not by flops",
             "latency_floor": {"model": "iterations x (0.1 ms + 0.11 ms per 128-row block) summed over the LPs, one LP at a "
                                        "time on one GPU (round-1 measurement, batch.predicted_cost)",
                               "chain_seconds_one_gpu": chain_s, "measured_wall_seconds": elapsed,
@@ -223,7 +228,8 @@ def netlib_cpu_baseline(names, probs, budget_s=15.0, tol_gap=None, max_iter=300)
     order = sorted(range(len(names)), key=lambda i: (probs[i][0].shape[0] * probs[i][0].shape[1], names[i]))
     done, conv, t0 = [], 0, time.perf_counter()
     for i in order:
-        if time.perf_counter() - t0 > budget_s:
+        # bounded: stop at the budget, and never start an LP whose dense m x m factor makes one solve take minutes
+        if time.perf_counter() - t0 > budget_s or probs[i][0].shape[0] > 1200:
             break
         A, b, c = probs[i]
         x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=1.0, method="normal", max_iter=max_iter, tol_gap=tol_gap)

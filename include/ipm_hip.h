@@ -159,7 +159,8 @@ int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, double* dy, d
 
 /* ---- solver seam ------------------------------------------------------------------- */
 /* Run exactly n_steps predictor-corrector iterations from the current state.  The stop
- * test is evaluated (stats) but not acted on: this is the benchmark entry point.  The residuals and the stop test
+ * test is evaluated (stats) but not acted on: this is the benchmark entry point.  The iteration count (and the
+ * history) restarts at 0 with the first call after ipm_set_state / ipm_init_state and continues over further calls.  The residuals and the stop test
  * are evaluated once more after the last step, so objective / norms / gap in `stats` describe the state
  * ipm_get_state returns (step lengths, mu_aff and sigma are those of the last step taken). */
 int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats);

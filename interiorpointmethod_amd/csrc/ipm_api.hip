@@ -17,6 +17,7 @@
 
 #include "../../include/ipm_hip.h"
 #include "gemm_nt_f64.h"
+#include "adat_syrk_f64.h"
 #include "potrf_f64.h"
 #include "sparse_ops.h"
 #include "trsv_grouped.h"
@@ -93,6 +94,7 @@ struct ipm_handle {
     int* fixed = nullptr;
     Scalars* h_sc = nullptr;          // pinned host mirror
     bool haveA = false, haveBC = false, haveState = false, predictor_valid = false;
+    bool fresh_state = true;              // the iterate was (re)set: the next ipm_iterate counts its steps from k = 0
     int profiling = 0;                    // 0 off, 1 events around the A D^2 A^T kernel only, 2 every phase
     double phase_ms[4] = {0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -508,7 +510,7 @@ extern "C" int ipm_set_state(ipm_handle* h, const double* x, const double* y, co
     HIP_TRY(h, hipMemcpyAsync(h->y, y, sizeof(double) * h->m, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->s, s, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->haveState = true; h->predictor_valid = false;
+    h->haveState = true; h->predictor_valid = false; h->fresh_state = true;
     return IPM_OK;
 }
 
@@ -537,7 +539,7 @@ extern "C" int ipm_init_state(ipm_handle* h, double y0) {
     int rc = enqueue_init_state(h, y0);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->haveState = true; h->predictor_valid = false;
+    h->haveState = true; h->predictor_valid = false; h->fresh_state = true;
     return IPM_OK;
 }
 
@@ -610,6 +612,11 @@ static int enqueue_form(ipm_handle* h, const double* d) {
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;
     g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = (int)h->m; g.done = &h->sc->done;
+    if (h->form_variant == 0 && h->np <= (1 << 20)) {      // dedicated software-pipelined kernel (adat_syrk_f64.h)
+        HIP_TRY(h, launch_adat_syrk(h->A, h->np, d, h->B, h->mp, (int)h->mp, (int)h->np, (int)h->m, &h->sc->done,
+                                    h->d_tile_order, h->stream, h->slab, 512));
+        return IPM_OK;
+    }
     switch (h->form_variant) {
         case 1: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream))); break;               // no split-K
         case 2: HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(g, h->stream, h->slab, 256))); break;  // BK=32, 1 wg/CU
@@ -617,7 +624,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
         case 4: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(g, h->stream, h->slab, 512))); break;
         case 5: g.w = nullptr; HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;  // timing probe: no d scaling (WRONG result)
         case 6: g.tile_order = nullptr; HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;  // timing probe: row-major tile order
-        default: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;
+        default: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;   // 7: generic kernel (round 1)
     }
     return IPM_OK;
 }
@@ -1074,8 +1081,11 @@ extern "C" int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats) {
         for (auto& e : evs) HIP_TRY(h, hipEventCreate(&e));
     }
     float ms = 0.f;
+    const int reset_k = h->fresh_state ? 1 : 0;      // iteration count and history restart with a newly set iterate
+    h->fresh_state = false;
     for (int attempt = 0;; ++attempt) {
-        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
+        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1,
+                           attempt == 0 ? reset_k : 0);
         const bool guard_poll = may_poll(h) && n_steps > 0;
         if (guard_poll && (rc = enqueue_snapshot(h, 0))) return rc;
         HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -1118,7 +1128,7 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     if (rc) return rc;
     if (max_iter < 0) return fail(h, IPM_ERR_INVALID_ARG, "max_iter < 0");
     HIP_TRY(h, hipSetDevice(h->device));
-    h->predictor_valid = false;
+    h->predictor_valid = false; h->fresh_state = false;
     if (h->auto_reg) { h->auto_reg = 0; h->shift_rel = h->opt.regularize; }      // decided per solve
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, tol_p, tol_d, tol_gap, h->opt.eta, max_iter, 0, 1);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));

@@ -67,6 +67,32 @@ def envelope_row_order(A, force=False):
     return None
 
 
+def factor_flops(A, nb=128):
+    """Flops of the blocked Cholesky of A A^T AS THE DEVICE RUNS IT for this A: dense handles and sparse handles whose
+    tile envelope removes less than 20 % of the work factor the full matrix (m^3/3); otherwise only the blocks inside
+    the tile envelope (after the reverse Cuthill-McKee row order where IpmSolver applies it) are touched:
+    sum over block columns of nb^3 (h^2 + 2 h + 1/3), h = envelope height in blocks below the diagonal block.
+    Used by bench.py for the roofline denominator of the Netlib runs -- STOCFOR3's factor is 11 % of m^3/3."""
+    m = A.shape[0]
+    if _sp is None or not _sp.issparse(A):
+        return m ** 3 / 3.0
+    P = _sp.csr_matrix(abs(A) @ abs(A).T)
+    P.data[:] = 1.0
+    if m >= REORDER_MIN_ROWS:
+        perm = envelope_row_order(A)
+        if perm is not None:
+            P = P[perm][:, perm]
+    work, dense = _tile_envelope_work(P, nb)
+    if not work < 0.8 * dense:                   # the library's rule (ipm_set_A_csc): the envelope must remove work
+        return m ** 3 / 3.0
+    Pc = P.tocoo()
+    nblk = (m + nb - 1) // nb
+    last = np.arange(nblk)
+    np.maximum.at(last, np.minimum(Pc.row, Pc.col) // nb, np.maximum(Pc.row, Pc.col) // nb)
+    hgt = (np.maximum.accumulate(last) - np.arange(nblk)).astype(np.float64)
+    return float(np.sum(nb ** 3 * (hgt * hgt + 2.0 * hgt + 1.0 / 3.0)))
+
+
 def _col(v, n, name):
     v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
     if v.shape[0] != n:

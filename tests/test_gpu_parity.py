@@ -604,7 +604,7 @@ def test_history_and_iterate_statistics(golden_dir):
         assert h[-1]["gap"] > st["gap"] and st["objective_last_finite"] == st["objective"]
         # ipm_iterate: statistics of the state reached, not of the one before the last step
         sv.init_state(1.0)
-        st3 = sv.iterate(3)
+        st3 = sv.iterate(3)                     # the count restarts with the newly set iterate
         x, y, s = sv.get_state()
         assert st3["iterations"] == 3
         assert np.isclose(st3["objective"], float((cf.T @ x).item()), rtol=1e-13)
@@ -613,6 +613,7 @@ def test_history_and_iterate_statistics(golden_dir):
         assert np.isclose(st3["rd_norm"], np.linalg.norm(Af.T @ y + s - cf), rtol=1e-9, atol=1e-13)
         h3 = sv.history()
         assert len(h3) == 3 and h3[0]["objective"] == h[0]["objective"] and h3[2]["alpha_p"] == h[2]["alpha_p"]
+        assert sv.iterate(2)["iterations"] == 5 and len(sv.history()) == 5      # ... and continues over further calls
 
 
 def test_nan_solve_returns_last_finite_objective():

@@ -1,0 +1,76 @@
+// syrk_bench.hip -- A/B timing of the dominant kernel (B = A diag(d) A^T) in ONE process, interleaved rounds
+// (cdna guide 5.4 rule 24): the generic gemm_nt_f64_kernel<128,128,16,2,2,true> against adat_syrk_kernel, on
+// random data, with a bit-for-bit comparison of the two results.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/syrk_bench tools/syrk_bench.hip
+//   tools/bin/syrk_bench [m n rounds]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "../interiorpointmethod_amd/csrc/gemm_nt_f64.h"
+#include "../interiorpointmethod_amd/csrc/adat_syrk_f64.h"
+using namespace ipm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static std::vector<int> tile_order(int nT) {
+    std::vector<int> order; const int PB = 8;
+    for (int I = 0; I * PB < nT; ++I)
+        for (int J = 0; J <= I; ++J)
+            for (int ti = I * PB; ti < nT && ti < (I + 1) * PB; ++ti)
+                for (int tj = J * PB; tj <= ti && tj < (J + 1) * PB; ++tj) order.push_back((ti << 16) | tj);
+    return order;
+}
+
+int main(int argc, char** argv) {
+    int m = argc > 1 ? atoi(argv[1]) : 4096, n = argc > 2 ? atoi(argv[2]) : 8192, rounds = argc > 3 ? atoi(argv[3]) : 10;
+    const size_t na = (size_t)m * n;
+    std::vector<double> hA(na), hd(n);
+    unsigned long long s = 88172645463325252ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+    for (auto& v : hA) v = 2.0 * rnd() - 1.0;
+    for (auto& v : hd) v = 0.5 + rnd();
+    double *A, *d, *B0, *B1, *slab; int* ord;
+    CK(hipMalloc(&A, na * 8)); CK(hipMalloc(&d, n * 8)); CK(hipMalloc(&B0, (size_t)m * m * 8)); CK(hipMalloc(&B1, (size_t)m * m * 8));
+    CK(hipMalloc(&slab, (size_t)kSlabTiles * 128 * 128 * 8));
+    auto ho = tile_order(m / 128);
+    CK(hipMalloc(&ord, ho.size() * 4));
+    CK(hipMemcpy(A, hA.data(), na * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d, hd.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ord, ho.data(), ho.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(B0, 0, (size_t)m * m * 8)); CK(hipMemset(B1, 0, (size_t)m * m * 8));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    auto run_old = [&]() {
+        GemmNT g; memset(&g, 0, sizeof g);
+        g.batch = 1; g.batch2 = 1; g.tile_order = ord; g.P = A; g.ldp = n; g.Q = A; g.ldq = n; g.w = d; g.C = B0; g.ldc = m;
+        g.M = m; g.N = m; g.K = n; g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = -1;
+        CK((launch_gemm_nt<128, 128, 16, 2, 2>(g, st, slab, 512)));
+    };
+    auto run_new = [&]() { CK(launch_adat_syrk(A, n, d, B1, m, m, n, -1, nullptr, ord, st, slab, 512)); };
+    run_old(); run_new(); CK(hipStreamSynchronize(st));
+    std::vector<double> h0((size_t)m * m), h1((size_t)m * m);
+    CK(hipMemcpy(h0.data(), B0, h0.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), B1, h1.size() * 8, hipMemcpyDeviceToHost));
+    size_t ndiff = 0; double maxd = 0;
+    for (int i = 0; i < m; ++i) for (int j = 0; j <= (i | 127) && j < m; ++j) {
+        double a = h0[(size_t)i * m + j], b = h1[(size_t)i * m + j];
+        if (a != b) { ++ndiff; maxd = std::max(maxd, fabs(a - b)); }
+    }
+    printf("compare old vs new: %zu differing entries, max |diff| %.3e (B[1][0]=%.6f)\n", ndiff, maxd, h0[(size_t)m]);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> t_old, t_new;
+    const int reps = 5;
+    for (int r = 0; r < rounds; ++r) {
+        float ms;
+        CK(hipEventRecord(e0, st)); for (int i = 0; i < reps; ++i) run_old(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); t_old.push_back(ms / reps);
+        CK(hipEventRecord(e0, st)); for (int i = 0; i < reps; ++i) run_new(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); t_new.push_back(ms / reps);
+    }
+    auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    auto mn = [](std::vector<float> v) { return *std::min_element(v.begin(), v.end()); };
+    const double fl = (double)m * m * n;
+    printf("m=%d n=%d  generic: median %.4f ms (%.1f TF) min %.4f | adat_syrk: median %.4f ms (%.1f TF, %.3f of 78.6) min %.4f\n", m, n,
+           med(t_old), fl / med(t_old) * 1e-9, mn(t_old), med(t_new), fl / med(t_new) * 1e-9, fl / med(t_new) * 1e-9 / 78.6, mn(t_new));
+    return 0;
+}

@@ -91,6 +91,25 @@ def test_dense_end_to_end(golden_dir, nm, method):
         assert abs(info["objective"] + 15000) < 1e-5        # main.py:1261
 
 
+def test_dense_1024x2048_normal_vs_reference(golden_dir):
+    """The normal-equations restatement against the reference-verbatim dense solve at 1024 x 2048 (fixture generated
+    by make_golden.py --only dense_large: 20 iterations of main.py:185-244 on the (m+2n)-order KKT system): same
+    iteration count, objective to 1e-9, iterate to 1e-6, and the reference's objective after every iteration."""
+    z = np.load(os.path.join(golden_dir, "dense_syn_1024x2048.npz"))
+    A, b, c = synthetic_lp(1024, 2048)
+    # b = A x0 and c = A^T y0 + s0 come out of a threaded BLAS matvec: the last bits depend on the thread count, so the
+    # LP the reference solved is taken from the fixture (b, c) and only compared loosely with the regenerated one
+    assert np.allclose(b, z["b"], rtol=1e-12, atol=1e-12) and np.allclose(c, z["c"], rtol=1e-12, atol=1e-12)
+    b, c = z["b"], z["c"]
+    traj = []
+    x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=0.0, method="normal", max_iter=200,
+                            callback=lambda k, x, y, s, it: traj.append(float((c.T @ x).item())))
+    ref = float(z["objective"])
+    assert info["iterations"] == int(z["iterations"]) == 20
+    assert abs(info["objective"] - ref) <= 1e-9 * max(1.0, abs(ref)) and rel(x, z["x"]) < 1e-6
+    assert np.allclose(traj, z["objective_after_iteration"], rtol=1e-8, atol=1e-8)
+
+
 E2E_SMALL = ["AFIRO", "SC50A", "SC50B", "SC105", "SC205", "KB2", "SHARE2B", "STOCFOR1", "E226", "BANDM", "SCSD1"]
 
 

@@ -24,6 +24,19 @@ static std::vector<int> tile_order(int nT) {
     return order;
 }
 
+// context probes: what the kernel sees inside the solver -- 2.8 ms of a nearly idle chip (the Cholesky pivot chain) and
+// ~0.5 GB of other traffic (B, L, the GEMV passes) between two formations
+__global__ void spin_kernel(long long cycles, double* sink) {
+    const long long t0 = clock64();
+    double x = 1.0;
+    while (clock64() - t0 < cycles) x = x * 1.0000001 + 1e-9;
+    if (x == 0.123) *sink = x;
+}
+__global__ void stream_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) dst[i] = src[i] + 1.0;
+}
+
 int main(int argc, char** argv) {
     int m = argc > 1 ? atoi(argv[1]) : 4096, n = argc > 2 ? atoi(argv[2]) : 8192, rounds = argc > 3 ? atoi(argv[3]) : 10;
     const size_t na = (size_t)m * n;
@@ -68,6 +81,23 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1)); t_new.push_back(ms / reps);
     }
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    if (argc > 4) {      // context probes (new kernel only): time ONE formation after (a) nothing, (b) an idle gap, (c) a cache flush, (d) both
+        double *f0, *f1; const size_t fn = (size_t)48 << 20;     // 2 x 384 MB
+        CK(hipMalloc(&f0, fn * 8)); CK(hipMalloc(&f1, fn * 8)); CK(hipMemset(f0, 0, fn * 8));
+        const char* names[4] = {"back to back", "after 2.8 ms on one workgroup", "after 0.77 GB of other traffic", "after both"};
+        for (int mode = 0; mode < 4; ++mode) {
+            std::vector<float> t;
+            for (int r = 0; r < 12; ++r) {
+                run_new();
+                if (mode & 2) hipLaunchKernelGGL(stream_kernel, dim3(2048), dim3(256), 0, st, f0, f1, fn);
+                if (mode & 1) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (long long)(2.8e-3 * 100e6 * 24), slab);   // clock64 ~ shader clock; ~2.8 ms at 2.4 GHz
+                float ms;
+                CK(hipEventRecord(e0, st)); run_new(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms);
+            }
+            printf("  one formation %-34s: median %.4f ms  min %.4f\n", names[mode], med(t), *std::min_element(t.begin(), t.end()));
+        }
+    }
     auto mn = [](std::vector<float> v) { return *std::min_element(v.begin(), v.end()); };
     const double fl = (double)m * m * n;
     printf("m=%d n=%d  generic: median %.4f ms (%.1f TF) min %.4f | adat_syrk: median %.4f ms (%.1f TF, %.3f of 78.6) min %.4f\n", m, n,

@@ -21,6 +21,7 @@
 #include "potrf_f64.h"
 #include "sparse_ops.h"
 #include "trsv_grouped.h"
+#include "small_lp.h"
 #include "vector_ops.h"
 
 #include <algorithm>
@@ -59,6 +60,13 @@ struct ipm_handle {
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     int last_gs = 1, n_counter_steps = 0, n_event_steps = 0, timeouts_recovered = 0;   // ipm_get_schedule
     bool counted = false;                 // this handle is in g_live
+    // fused single-workgroup path for small sparse LPs (small_lp.h): product list of B's lower entries, own allocation
+    bool small = false;
+    int fused_small = 1;                  // IPM_FUSED_SMALL=0: always the multi-kernel path
+    int sm_nb = 0;
+    int *sm_bptr = nullptr, *sm_bcol = nullptr;
+    unsigned short *sm_bi = nullptr, *sm_bk = nullptr;
+    double* sm_bcoef = nullptr;
     double shift_rel = 0.0;               // Tikhonov shift in effect (opt.regularize, or 1e-14 switched on by ipm_solve)
     int auto_reg = 0;                     // 1: the shift was switched on automatically
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
@@ -340,6 +348,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
+    if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -382,6 +391,8 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->gX) (void)hipFree(h->gX);
     if (h->gS) (void)hipFree(h->gS);
     if (h->gPart) (void)hipFree(h->gPart);
+    for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef})
+        if (p) (void)hipFree(p);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -467,6 +478,56 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
             h->use_env = h->envelope != 0 && work < 0.8 * dense;         // only when it actually removes work
         }
         h->nnz = nz; h->haveA = true; h->predictor_valid = false;
+        h->small = false;
+        if (h->fused_small && h->m <= SMALL_MAX_M) {
+            // product list of the fused small-LP kernel: lower entry (i, k) of B = A diag(d) A^T is
+            // sum_t coef[t] d[col[t]] over the columns that rows i and k share (coef = a_ij a_kj); entries ordered
+            // by (i, k), terms by column: a fixed summation order
+            size_t terms = 0;
+            for (int64_t j = 0; j < h->n; ++j) { const size_t c = (size_t)(cp[j + 1] - cp[j]); terms += c * (c + 1) / 2; }
+            if (terms <= ((size_t)1 << 22)) {
+                const int M = (int)h->m;
+                std::vector<int> cnt((size_t)M * M, 0);
+                for (int64_t j = 0; j < h->n; ++j)
+                    for (int p = cp[j]; p < cp[j + 1]; ++p)
+                        for (int q = cp[j]; q <= p; ++q) cnt[(size_t)ri[p] * M + ri[q]]++;          // ri sorted: ri[p] >= ri[q]
+                std::vector<int> bptr(1, 0), slot((size_t)M * M, -1);
+                std::vector<unsigned short> bi, bk;
+                for (int i = 0; i < M; ++i)
+                    for (int k = 0; k <= i; ++k)
+                        if (cnt[(size_t)i * M + k] > 0 || i == k) {                                  // the diagonal always exists
+                            slot[(size_t)i * M + k] = (int)bi.size();
+                            bi.push_back((unsigned short)i); bk.push_back((unsigned short)k);
+                            bptr.push_back(bptr.back() + cnt[(size_t)i * M + k]);
+                        }
+                std::vector<int> fill(bptr.begin(), bptr.end() - 1), bcol((size_t)bptr.back());
+                std::vector<double> bcoef((size_t)bptr.back());
+                for (int64_t j = 0; j < h->n; ++j)                                                   // j ascending: terms of an entry sorted by column
+                    for (int p = cp[j]; p < cp[j + 1]; ++p)
+                        for (int q = cp[j]; q <= p; ++q) {
+                            const int e = slot[(size_t)ri[p] * M + ri[q]];
+                            const int t = fill[e]++;
+                            bcol[t] = (int)j; bcoef[t] = cv[p] * cv[q];
+                        }
+                for (void** p : {(void**)&h->sm_bptr, (void**)&h->sm_bcol, (void**)&h->sm_bi, (void**)&h->sm_bk, (void**)&h->sm_bcoef})
+                    if (*p) { (void)hipFree(*p); *p = nullptr; }
+                h->sm_nb = (int)bi.size();
+                const size_t nt_ = bcol.size() ? bcol.size() : 1;
+                HIP_TRY(h, hipMalloc((void**)&h->sm_bptr, sizeof(int) * bptr.size()));
+                HIP_TRY(h, hipMalloc((void**)&h->sm_bi, sizeof(unsigned short) * bi.size()));
+                HIP_TRY(h, hipMalloc((void**)&h->sm_bk, sizeof(unsigned short) * bk.size()));
+                HIP_TRY(h, hipMalloc((void**)&h->sm_bcol, sizeof(int) * nt_));
+                HIP_TRY(h, hipMalloc((void**)&h->sm_bcoef, sizeof(double) * nt_));
+                HIP_TRY(h, hipMemcpy(h->sm_bptr, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpy(h->sm_bi, bi.data(), sizeof(unsigned short) * bi.size(), hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpy(h->sm_bk, bk.data(), sizeof(unsigned short) * bk.size(), hipMemcpyHostToDevice));
+                if (!bcol.empty()) {
+                    HIP_TRY(h, hipMemcpy(h->sm_bcol, bcol.data(), sizeof(int) * bcol.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpy(h->sm_bcoef, bcoef.data(), sizeof(double) * bcoef.size(), hipMemcpyHostToDevice));
+                }
+                h->small = true;
+            }
+        }
         return IPM_OK;
     }
     // dense row-major image of A (scattered on the host, one upload)
@@ -1065,6 +1126,21 @@ extern "C" int ipm_get_phase_ms(ipm_handle* h, double out[4]) {
     return IPM_OK;
 }
 
+// whole loop of a small sparse LP in one launch of one workgroup (small_lp.h)
+static int enqueue_small(ipm_handle* h, int max_steps, int auto_reg) {
+    SmallLP a;
+    a.A = sparse_view(h); a.m = (int)h->m; a.n = (int)h->n; a.nt = (int)((h->m + 15) / 16);
+    a.bptr = h->sm_bptr; a.bi = h->sm_bi; a.bk = h->sm_bk; a.bcol = h->sm_bcol; a.bcoef = h->sm_bcoef; a.nb = h->sm_nb;
+    a.x = h->x; a.y = h->y; a.s = h->s; a.b = h->b; a.c = h->c;
+    a.rc = h->rc; a.d = h->d; a.v = h->v; a.q = h->q; a.dxa = h->dxa; a.dsa = h->dsa; a.dx = h->dx; a.ds = h->ds;
+    a.sc = h->sc; a.hist = h->hist;
+    a.eps = h->opt.pivot_guard_eps; a.big = h->opt.pivot_guard_big; a.shift_rel = h->shift_rel;
+    a.max_steps = max_steps; a.auto_reg = auto_reg;
+    hipLaunchKernelGGL(small_lp_kernel, dim3(1), dim3(PD_THREADS), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return IPM_OK;
+}
+
 extern "C" int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats) {
     int rc = check_ready(h, "ipm_iterate");
     if (rc) return rc;
@@ -1083,6 +1159,16 @@ extern "C" int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats) {
     float ms = 0.f;
     const int reset_k = h->fresh_state ? 1 : 0;      // iteration count and history restart with a newly set iterate
     h->fresh_state = false;
+    if (h->small && !h->profiling) {
+        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, reset_k);
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        if ((rc = enqueue_small(h, n_steps, 0))) return rc;
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        if ((rc = read_scalars(h))) return rc;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        fill_stats(h, stats, ms);
+        return IPM_OK;
+    }
     for (int attempt = 0;; ++attempt) {
         hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1,
                            attempt == 0 ? reset_k : 0);
@@ -1134,6 +1220,24 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     const int chunk = h->opt.check_every;
     const bool may_auto = h->opt.regularize == 0.0 && !(h->opt.flags & IPM_FLAG_NO_AUTO_REGULARIZE);
+    if (h->small) {
+        // one launch runs the loop to its end; a second one only when the first factorization asked for the shift
+        // (the kernel leaves before it touches the iterate, so there is nothing to roll back)
+        if ((rc = enqueue_small(h, 1 << 30, may_auto ? 1 : 0))) return rc;
+        if ((rc = read_scalars(h))) return rc;
+        if (h->h_sc->status == IPM_STATUS_NEEDS_SHIFT) {
+            h->shift_rel = 1e-14; h->auto_reg = 1;
+            hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, tol_p, tol_d, tol_gap, h->opt.eta, max_iter, 0, 1);
+            if ((rc = enqueue_small(h, 1 << 30, 0))) return rc;
+            if ((rc = read_scalars(h))) return rc;
+        }
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms_ = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms_, h->ev0, h->ev1));
+        fill_stats(h, stats, ms_);
+        return IPM_OK;
+    }
     bool first = true;
     int recovered = 0;
     for (;;) {
@@ -1194,7 +1298,7 @@ extern "C" int ipm_get_schedule(ipm_handle* h, int32_t out[10]) {
     out[0] = h->nblk; out[1] = h->last_gs; out[2] = h->grouped_trsv;
     out[3] = (may_poll(h) && live <= 1) ? 1 : 0;
     out[4] = h->n_counter_steps; out[5] = h->n_event_steps; out[6] = h->use_env ? 1 : 0; out[7] = live;
-    out[8] = h->timeouts_recovered; out[9] = 0;
+    out[8] = h->timeouts_recovered; out[9] = h->small ? 1 : 0;
     return IPM_OK;
 }
 

@@ -69,13 +69,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& root, double& rinv)
 //   X[i][j]   (j <= i)  at W[j*WLD + i + 1]      X = inv(L), stored transposed one column right
 // so the strict upper part of the square holds the inverse without a second array.
 //
-// Schedule (jb = 16-wide panel index, 4 waves):
-//   P2(jb): threads 0..16*nrt-1 forward-substitute their row of the panel below tile jb
-//           (registers, T broadcast from LDS); wave 3 meanwhile inverts tile jb.
-//   P3(jb): wave 0 updates tile (jb+1,jb+1) and immediately factors it (runs ahead on the
-//           serial pivot chain); waves 1-3 do the rest of the trailing update and then block
-//           row jb of inv(L) (work that grows as the update shrinks).
-// Two barriers per panel.
+// The schedule of a factorization (8 waves, two barriers per 16-wide panel) is documented at potrf_lds() below.
 
 // 1/p from v_rcp_f64 (about 23 good bits) and one cubic step y(1 + e + e^2), e = 1 - p y.
 __device__ __forceinline__ double fast_rcp(double p) {
@@ -289,48 +283,23 @@ __device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, 
 }
 
 // STAMP = true is a diagnostic instantiation (tools/potrf_stamps.py): every wave records s_memtime
-// at each phase boundary into a.stamps[wave*64 + slot]; the production kernel carries no stamps.
-#define IPM_STAMP(slot) do { if (STAMP && lane == 0) a.stamps[wave * 64 + (slot)] = (long long)clock64(); } while (0)
+// at each phase boundary into stamps[wave*64 + slot]; the production kernel carries no stamps.
+#define IPM_STAMP(slot) do { if (STAMP && lane == 0) stamps[wave * 64 + (slot)] = (long long)clock64(); } while (0)
 constexpr int PD_THREADS = 512;      // 8 waves: wave 0 runs the serial pivot chain, waves 1..7 the MFMA work
 
+// Guarded Cholesky of the leading 16 nt x 16 nt block held in the LDS workspace W (layout above), by one workgroup of
+// PD_THREADS threads: on return L sits in the lower triangle and X = inv(L) in the shifted upper triangle, dinv_s[i] =
+// 1 / L[i][i].  W must hold the lower triangle AND the full symmetric 16 x 16 diagonal tiles on entry; all waves must
+// have passed a barrier after the last write to W.  Returns the number of guarded pivots (meaningful on wave 0).
+// nt = 8 is the 128 x 128 diagonal block of the blocked factorization (potrf_diag_kernel); the fused small-LP kernel
+// (small_lp.h) calls it with nt = ceil(m / 16).
 template <bool STAMP>
-__global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
-    if (a.done && *a.done) return;
-    __shared__ __attribute__((aligned(16))) double W[NB * WLD];
-    __shared__ double dinv_s[NB];
-
+__device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, double thresh, double big, long long* stamps) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
-    const double thresh = a.eps * (*a.maxdiag);
-
-    IPM_STAMP(0);
-    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a
-    //      thread are issued before the first LDS write (one memory latency)
-    {
-        f64x2 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            int idx = tid + u * PD_THREADS;
-            int i = idx >> 6, c2 = (idx & 63) * 2;
-            v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            int idx = tid + u * PD_THREADS;
-            int i = idx >> 6, c2 = (idx & 63) * 2;
-            if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
-        }
-    }
-    if (a.shift_rel != 0.0) {
-        __syncthreads();
-        if (tid < NB) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
-    }
-    __syncthreads();
-    IPM_STAMP(1);
-
     int nfix = 0;
-    if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, a.big, dinv_s);
+    if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, big, dinv_s);
     IPM_STAMP(2);
     __syncthreads();
     IPM_STAMP(3);
@@ -341,9 +310,9 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     //           wave 7 : invert tile jb, then shares the item list
     //           waves 1..6: item list = rest of the trailing update of panel jb, then block row jb-1 of
     //                       inv(L) (its diagonal tile inverse was produced in P3(jb-1))
-    for (int jb = 0; jb < NB / 16; ++jb) {
+    for (int jb = 0; jb < nt; ++jb) {
         const int c0 = jb * 16;
-        const int nrt = NB / 16 - jb - 1;                 // 16-row tiles below the pivot tile
+        const int nrt = nt - jb - 1;                      // 16-row tiles below the pivot tile
         if (nrt > 0) {
             double trow[16];
 #pragma unroll
@@ -359,7 +328,7 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
         IPM_STAMP(5 + jb * 4);
         if (wave == 0 && nrt > 0) {
             const f64x4 nxt = update_tile_regs(W, c0, c0 + 16, c0 + 16, fr, fk);     // stays in registers
-            nfix += factor_tile(W, c0 + 16, lane, thresh, a.big, dinv_s, &nxt);
+            nfix += factor_tile(W, c0 + 16, lane, thresh, big, dinv_s, &nxt);
         } else {
             // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1.
             // Wave 7 only inverts tile jb (about as long as wave 0's factorization) while a pivot tile is
@@ -387,11 +356,51 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
         __syncthreads();
         IPM_STAMP(7 + jb * 4);
     }
-    // last block row of inv(L): needs the tile inverse of panel 7 (made in P3(7)) and row 6 (also P3(7))
-    for (int jt = wave; jt < NB / 16 - 1; jt += 8) inverse_tile(W, NB / 16 - 1, jt, fr, fk);
+    // last block row of inv(L): needs the tile inverse of the last panel (made in its P3) and the row above it
+    for (int jt = wave; jt < nt - 1; jt += 8) inverse_tile(W, nt - 1, jt, fr, fk);
     IPM_STAMP(38);
     __syncthreads();
     IPM_STAMP(39);
+    return nfix;
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
+    if (a.done && *a.done) return;
+    __shared__ __attribute__((aligned(16))) double W[NB * WLD];
+    __shared__ double dinv_s[NB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double thresh = a.eps * (*a.maxdiag);
+    long long* stamps = a.stamps;
+
+    IPM_STAMP(0);
+    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a
+    //      thread are issued before the first LDS write (one memory latency)
+    {
+        f64x2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int idx = tid + u * PD_THREADS;
+            int i = idx >> 6, c2 = (idx & 63) * 2;
+            v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int idx = tid + u * PD_THREADS;
+            int i = idx >> 6, c2 = (idx & 63) * 2;
+            if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
+        }
+    }
+    if (a.shift_rel != 0.0) {
+        __syncthreads();
+        if (tid < NB) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
+    }
+    __syncthreads();
+    IPM_STAMP(1);
+
+    const int nfix = potrf_lds<STAMP>(W, dinv_s, NB / 16, thresh, a.big, stamps);
 
     // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero
     //      from the handle's initial memset and is never written)

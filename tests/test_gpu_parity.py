@@ -590,6 +590,52 @@ def test_general_form_all_fixtures_with_mehrotra_start(golden_dir):
     assert done >= 40
 
 
+SMALL_LPS = ["AFIRO", "ADLITTLE", "KB2", "SC105", "SC50A", "SC50B", "SCSD1", "SHARE1B", "SHARE2B", "STOCFOR1"]
+
+
+@pytest.mark.parametrize("name", SMALL_LPS)
+def test_fused_small_lp_path(golden_dir, monkeypatch, name):
+    """The 10 Netlib files with m <= 128 run their whole loop in ONE launch of one workgroup (small_lp.h).  Against
+    the multi-kernel path (IPM_FUSED_SMALL=0) on the same LP: same status; where both converge the same objective
+    to 1e-8 and iteration counts within 2 (summation orders differ, trajectories are chaotic: SURVEY H1); bitwise
+    repeatable; history, iterate() and the stop test on the host behave as on the other path.  The reference
+    comparison itself is test_netlib_parity (8 of these 10 are in the parity set and now take the fused path)."""
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    Af, bf, cf = O.as_float64_problem(A, b, c)
+    with ipm.IpmSolver(A, b, c) as sv:
+        assert sv.schedule()["fused_small"] == 1
+        sv.init_state(1.0)
+        st = sv.solve(tol=1e-8, max_iter=300)
+        x, y, s = sv.get_state()
+        hist = sv.history()
+        sv.init_state(1.0)
+        st_b = sv.solve(tol=1e-8, max_iter=300)
+        assert st_b["iterations"] == st["iterations"] and np.array_equal(sv.get_state()[0], x)      # reproducible
+        sv.init_state(1.0)
+        it2 = sv.iterate(2)
+        x2, y2, s2 = sv.get_state()
+        assert it2["iterations"] == 2 and np.isclose(it2["gap"], float((x2.T @ s2).item()), rtol=1e-12)
+        assert np.isclose(it2["rp_norm"], np.linalg.norm(Af @ x2 - bf), rtol=1e-9, atol=1e-12)
+    monkeypatch.setenv("IPM_FUSED_SMALL", "0")
+    with ipm.IpmSolver(A, b, c) as mk:
+        assert mk.schedule()["fused_small"] == 0
+        mk.init_state(1.0)
+        ref = mk.solve(tol=1e-8, max_iter=300)
+        mk.init_state(1.0)
+        mk.iterate(2)
+        xm, ym, sm = mk.get_state()
+    assert rel(x2, xm) < 1e-9 and rel(y2, ym) < 1e-9 and rel(s2, sm) < 1e-9            # two iterations: rounding only
+    assert st["status"] == ref["status"], (st["status"], ref["status"])
+    assert len(hist) == min(st["iterations"], 1024) and all(r["k"] == i for i, r in enumerate(hist))
+    if st["status"] == 1:
+        assert abs(st["iterations"] - ref["iterations"]) <= 2
+        assert abs(st["objective"] - ref["objective"]) <= 1e-8 * max(1.0, abs(ref["objective"]))
+        assert not O.check_optimality(Af, bf, cf, x, y, s, 1e-8, 1e-8, 1e-8)
+    if name == "AFIRO":
+        assert st["solve_ms"] < 4.0, st["solve_ms"]         # 93 iterations; the multi-kernel path needs ~10 ms
+        print("AFIRO fused %.3f ms, multi-kernel %.3f ms" % (st["solve_ms"], ref["solve_ms"]))
+
+
 def test_history_and_iterate_statistics(golden_dir):
     """ipm_get_history: one record per iteration (the line the reference prints, main.py:808-809/:1186), consistent
     with the final statistics; ipm_iterate's statistics describe the state ipm_get_state returns."""
@@ -600,7 +646,7 @@ def test_history_and_iterate_statistics(golden_dir):
         st = sv.solve(tol=1e-8, max_iter=500)
         h = sv.history()
         assert st["status"] == 1 and len(h) == st["iterations"] and [r["k"] for r in h] == list(range(len(h)))
-        assert h[0]["objective"] == float(np.sum(cf)) and h[0]["mu"] == 1.0            # x = s = 1 at the start
+        assert np.isclose(h[0]["objective"], float(np.sum(cf)), rtol=1e-14) and h[0]["mu"] == 1.0   # x = s = 1 at the start
         assert all(0.0 < r["alpha_p"] <= 0.91 and 0.0 < r["alpha_d"] <= 0.91 for r in h)   # eta = 0.91, main.py:607
         assert h[-1]["gap"] > st["gap"] and st["objective_last_finite"] == st["objective"]
         # ipm_iterate: statistics of the state reached, not of the one before the last step

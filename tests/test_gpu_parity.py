@@ -610,7 +610,7 @@ def test_fused_small_lp_path(golden_dir, monkeypatch, name):
         hist = sv.history()
         sv.init_state(1.0)
         st_b = sv.solve(tol=1e-8, max_iter=300)
-        assert st_b["iterations"] == st["iterations"] and np.array_equal(sv.get_state()[0], x)      # reproducible
+        assert st_b["iterations"] == st["iterations"] and np.array_equal(sv.get_state()[0], x, equal_nan=True)   # reproducible (SHARE1B ends in NaN, like the reference's loop on it)
         sv.init_state(1.0)
         it2 = sv.iterate(2)
         x2, y2, s2 = sv.get_state()

@@ -804,6 +804,27 @@ def test_netlib_suite_batched_config4(golden_dir):
     assert batch.summarize(par)["total_iterations"] == batch.summarize(seq)["total_iterations"]
 
 
+def test_results_table_against_reference_log(tmp_path):
+    """tools/netlib_report.py (the table of script.py:139-198) over general-form inputs the reference's own log
+    covers: the "Interi" column must print what conclusion1.txt:3,6 printed for AFIRO and BANDM (2 decimals), and
+    the Netlib and SciPy columns agree with them."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("netlib_report", os.path.join(root, "tools", "netlib_report.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    from interiorpointmethod_amd import general_form as GF
+    solve = lambda c, Aineq, bineq, Aeq, beq, lb, ub: GF.new_interior_sparse(                   # noqa: E731
+        c=c, Aineq=Aineq, bineq=bineq, Aeq=Aeq, beq=beq, lb=lb, ub=ub, tol=1e-6)
+    rows = R.run_general(["AFIRO", "BANDM"], solve)
+    out = os.path.join(tmp_path, "conclusion_gpu.txt")
+    R.write_table(rows, out)
+    lines = open(out, newline="").read().split("\r\n")
+    got = {ln.split()[0]: ln.split()[3:] for ln in lines[1:] if ln}
+    assert got["AFIRO"] == ["-464.75", "-464.75", "-464.75"]          # conclusion1.txt:3
+    assert got["BANDM"] == ["-158.63", "-158.63", "-158.63"]          # conclusion1.txt:6
+
+
 def test_batch_two_at_a_time_same_records(golden_dir):
     """Batched mode with two LPs in flight per GPU (host threads, own streams, IPM_FLAG_NO_DEVICE_POLLING): the
     records equal the one-at-a-time run bit for bit -- only the synchronisation mechanism differs."""

@@ -80,3 +80,56 @@ def test_envelope_row_order_recovers_a_staircase():
     assert before > 0.8 * dense and after < 0.15 * dense
     # a matrix whose normal matrix is dense gains nothing: no reordering
     assert S.envelope_row_order(sparse.csr_matrix(np.random.default_rng(1).standard_normal((300, 400)))) is None
+
+
+def test_results_table_layout_matches_reference_log(tmp_path):
+    """tools/netlib_report.py writes the table of the reference driver (script.py:139-198).  The header and the AFIRO
+    row of the reference's own log (conclusion1.txt:1 and :3, quoted here as data) are reproduced character for
+    character from the same numbers; the SciPy column is computed on the host exactly as script.py:155-164 does."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("netlib_report", os.path.join(root, "tools", "netlib_report.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    ref_header = "Name                    Interi time           Scipy time              Obj fun               Interi                Scipy"
+    ref_afiro = "AFIRO                          0.40                 0.03              -464.75              -464.75              -464.75"
+    assert R.header().rstrip("\r\n") == ref_header
+    assert R.row("AFIRO", -464.75314286, 0.40, 0.03, -464.7531428, -464.753142).rstrip("\r\n") == ref_afiro
+    calls = []
+
+    def stub(c, Aineq, bineq, Aeq, beq, lb, ub):          # stands in for the GPU solve on a GPU-less host
+        calls.append(c.shape[0])
+        return -464.7531
+    rows = R.run_general(["AFIRO"], stub, with_scipy=True)
+    assert calls and rows[0][0] == "AFIRO" and abs(rows[0][1] - (-464.75314286)) < 1e-6        # Netlib optimum column
+    assert abs(rows[0][5] - (-464.7531)) < 1e-3                                                 # SciPy on the host
+    out = os.path.join(tmp_path, "t.txt")
+    R.write_table(rows, out)
+    lines = open(out, newline="").read().split("\r\n")
+    assert lines[0] == ref_header and lines[1].split()[0] == "AFIRO" and lines[1].split()[3:] == ["-464.75"] * 3
+
+
+def test_bench_netlib_helpers():
+    """bench.py's Netlib leg: the parity set loads (26 LPs), the flop model uses the tile envelope where the device
+    does (STOCFOR3's factor is ~12 % of m^3/3), the roofline record has the contract keys, and a PMC file collected
+    for another kernel source is refused."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    names, probs, flops = B.load_netlib("parity")
+    assert len(names) == 26 and names == sorted(B.PARITY_SET)
+    i = names.index("STOCFOR3")
+    m = probs[i][0].shape[0]
+    assert 0.05 * m ** 3 / 3 < flops[i] < 0.25 * m ** 3 / 3
+    j = names.index("AFIRO")
+    assert flops[j] > 27 ** 3 / 3
+    rec = np.zeros((26, batch.NF)); rec[:, 0] = np.arange(26); rec[:, 1] = 1; rec[:, 2] = 30; rec[:, 7] = 0.01
+    rf = B.netlib_roofline(names, probs, flops, rec, 1.0, 1)
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf) and 0 < rf["frac"] < 1
+    assert rf["latency_floor"]["chain_seconds_one_gpu"] > 0
+    t, why = B.load_traffic(4096, 8192)
+    assert (t is None and ("stale" in why or "no PMC" in why or "shape" in why)) or t > 0
+    assert len(B.kernel_source_sha()) == 16

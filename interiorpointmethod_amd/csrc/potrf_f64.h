@@ -293,8 +293,11 @@ constexpr int PD_THREADS = 512;      // 8 waves: wave 0 runs the serial pivot ch
 // have passed a barrier after the last write to W.  Returns the number of guarded pivots (meaningful on wave 0).
 // nt = 8 is the 128 x 128 diagonal block of the blocked factorization (potrf_diag_kernel); the fused small-LP kernel
 // (small_lp.h) calls it with nt = ceil(m / 16).
-template <bool STAMP>
-__device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, double thresh, double big, long long* stamps) {
+struct NoEarlyWork { __device__ __forceinline__ void operator()() const {} };
+
+template <bool STAMP, typename Early = NoEarlyWork>
+__device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, double thresh, double big, long long* stamps,
+                                         Early early = Early()) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
@@ -356,8 +359,12 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
         __syncthreads();
         IPM_STAMP(7 + jb * 4);
     }
-    // last block row of inv(L): needs the tile inverse of the last panel (made in its P3) and the row above it
+    // last block row of inv(L): needs the tile inverse of the last panel (made in its P3) and the row above it.
+    // `early` (optional): work that only READS what is already final -- L and the inverse rows above the last one -- runs
+    // here, per wave, right behind that wave's tile of the last row: the tiles are uneven (nt-1 ... 1 products), so the
+    // write-back of the blocked factorization hides under the longest of them instead of following it.
     for (int jt = wave; jt < nt - 1; jt += 8) inverse_tile(W, nt - 1, jt, fr, fk);
+    early();
     IPM_STAMP(38);
     __syncthreads();
     IPM_STAMP(39);
@@ -400,26 +407,28 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     __syncthreads();
     IPM_STAMP(1);
 
-    const int nfix = potrf_lds<STAMP>(W, dinv_s, NB / 16, thresh, a.big, stamps);
-
-    // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero
-    //      from the handle's initial memset and is never written)
-#pragma unroll 8
-    for (int u = 0; u < 16; ++u) {
-        int idx = tid + u * PD_THREADS;
-        int i = idx >> 6, j = (idx & 63) * 2;
-        if (j <= i) {
-            double l0 = W[i * WLD + j], l1 = W[i * WLD + j + 1];
-            double x0 = W[j * WLD + i + 1];
-            if (j + 1 <= i) {
-                *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){l0, l1};
-                *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){x0, W[(j + 1) * WLD + i + 1]};
-            } else {
-                a.Bkk[(int64_t)i * a.ld + j] = l0;
-                a.inv[i * NB + j] = x0;
+    // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero from the handle's
+    //      initial memset and is never written).  Rows 0..111 of the inverse and all of L are final before the last
+    //      inverse row is assembled and are written under it (see potrf_lds); rows 112..127 of the inverse follow.
+    auto write_rows = [&](int u0, int u1, bool want_l, int inv_lo, int inv_hi) {
+        for (int u = u0; u < u1; ++u) {
+            int idx = tid + u * PD_THREADS;
+            int i = idx >> 6, j = (idx & 63) * 2;
+            if (j <= i) {
+                const bool wi = i >= inv_lo && i < inv_hi;
+                if (j + 1 <= i) {
+                    if (want_l) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){W[i * WLD + j], W[i * WLD + j + 1]};
+                    if (wi) *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){W[j * WLD + i + 1], W[(j + 1) * WLD + i + 1]};
+                } else {
+                    if (want_l) a.Bkk[(int64_t)i * a.ld + j] = W[i * WLD + j];
+                    if (wi) a.inv[i * NB + j] = W[j * WLD + i + 1];
+                }
             }
         }
-    }
+    };
+    const int nfix = potrf_lds<STAMP>(W, dinv_s, NB / 16, thresh, a.big, stamps,
+                                      [&]() { write_rows(0, 16, true, 0, NB - 16); });
+    write_rows(14, 16, false, NB - 16, NB);           // u = 14, 15 cover rows 112..127
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
 }

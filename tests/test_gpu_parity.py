@@ -414,18 +414,43 @@ def test_invalid_inputs_rejected(golden_dir):
 
 
 # ------------------------------------------------------------------ BASELINE.json full size
-def test_dense_4096x8192_full_solve():
-    """configs[1]: converges in 24 iterations to the value pinned in BASELINE.md 2.2."""
-    A, b, c = synthetic_lp(4096, 8192)
+def test_dense_4096x8192_full_solve(golden_dir):
+    """configs[1] against the REFERENCE ITSELF: tests/golden/dense_syn_4096x8192.npz holds the verbatim dense solve of
+    this LP by the reference's own step functions (main.py:185-244, 604-697; two LAPACK gesv of a 20480^2 KKT matrix
+    per iteration, 40 minutes in the build container): 24 iterations, objective -3.7612544745317e+02, the final
+    (x, y, s), the objective after every iteration and the first step's scalars."""
+    z = np.load(os.path.join(golden_dir, "dense_syn_4096x8192.npz"))
+    A, _, _ = synthetic_lp(4096, 8192)
+    b, c = z["b"], z["c"]                 # the LP the reference solved (threaded matvec: last bits differ per host)
     with ipm.IpmSolver(A, b, c) as sv:
+        sv.init_state(0.0)
+        da = sv.newton_direction(False)                       # reference: direction_predicted (full KKT, LAPACK gesv)
+        dc = sv.newton_direction(True)                        # reference: direction_corrected
+        for g, nm in zip(da + dc, ("dxa", "dya", "dsa", "dx", "dy", "ds")):
+            assert rel(g, z["k0_" + nm]) < 1e-9, nm
+        sv.init_state(0.0)
+        first = sv.iterate(1)
+        xn, yn, sn = sv.get_state()
+        assert rel(xn, z["k0_xn"]) < 1e-10 and rel(yn, z["k0_yn"]) < 1e-10 and rel(sn, z["k0_sn"]) < 1e-10
         sv.init_state(0.0)
         st = sv.solve(tol=1e-8, max_iter=200)
         x, y, s = sv.get_state()
+        hist = sv.history()
         sv.init_state(0.0)
         st2 = sv.solve(tol=1e-8, max_iter=200)
         x2, _, _ = sv.get_state()
-    assert st["status"] == 1 and abs(st["iterations"] - 24) <= 2
-    assert abs(st["objective"] - (-3.761254474176e+02)) <= 1e-6 * 3.77e2
+    # first step: the reference's ratio tests, centering and damped step lengths (main.py:305-322, 588-626)
+    assert np.isclose(first["alpha_aff_p"], float(z["k0_alpha_aff_p"]), rtol=1e-9)
+    assert np.isclose(first["alpha_aff_d"], float(z["k0_alpha_aff_d"]), rtol=1e-9)
+    assert np.isclose(first["sigma"], float(z["k0_sigma"]), rtol=1e-8)
+    assert np.isclose(first["alpha_p"], float(z["k0_alpha_p"]), rtol=1e-9) and np.isclose(first["alpha_d"], float(z["k0_alpha_d"]), rtol=1e-9)
+    # whole solve: iteration count, objective, iterate, and the objective trajectory
+    ref = float(z["objective"])
+    assert st["status"] == 1 and st["iterations"] == int(z["iterations"]) == 24
+    assert abs(st["objective"] - ref) <= 1e-9 * abs(ref)
+    assert rel(x, z["x"]) < 1e-6 and rel(s, z["s"]) < 1e-6 and rel(y, z["y"]) < 1e-6
+    traj = np.array([r["objective"] for r in hist[1:]] + [st["objective"]])        # objective after iteration 1..24
+    assert np.allclose(traj, z["objective_after_iteration"], rtol=1e-8, atol=1e-8)
     # size-independent properties: feasibility, complementarity, weak duality gap closes
     rb = A @ x - b
     rc = A.T @ y + s - c

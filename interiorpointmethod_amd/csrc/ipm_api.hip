@@ -18,6 +18,7 @@
 #include "../../include/ipm_hip.h"
 #include "gemm_nt_f64.h"
 #include "adat_syrk_f64.h"
+#include "chol_crit_f64.h"
 #include "potrf_f64.h"
 #include "sparse_ops.h"
 #include "trsv_grouped.h"
@@ -56,7 +57,8 @@ struct ipm_handle {
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
     int bulk_variant = 0;                 // 1: BK=32 tiles for the bulk trailing update (measured slower: 2.38 vs 2.26 ms)
-    int crit_variant = 1;                 // smaller tiles / deeper K steps for the two critical-path GEMMs
+    int crit_variant = 2;                 // critical-path GEMMs: 2 = single-stage register kernels (chol_crit_f64.h), 1 = 32-row
+                                          // tiles of the generic kernel (round 1), 0 = its plain tiles
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     int last_gs = 1, n_counter_steps = 0, n_event_steps = 0, timeouts_recovered = 0;   // ipm_get_schedule
     bool counted = false;                 // this handle is in g_live
@@ -775,7 +777,13 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         if (crit_flag) tc.signal = h->d_bulk_done + h->nblk + k;
         // NOTE the panel solve is IN PLACE (C = P): a workgroup must own whole rows, i.e. BN == N == 128.  Tiles narrower
         // than the panel (tried: 16 workgroups of 32 x 32) race -- one workgroup overwrites columns another still reads.
-        if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
+        const bool crit_regs = h->crit_variant == 2;         // single-stage register kernels: one memory latency per kernel
+        if (crit_regs) {
+            CritStep cs;
+            cs.panel = panel; cs.ld = h->mp; cs.inv = pd.inv; cs.C = nullptr; cs.ldc = 0; cs.done = done;
+            cs.signal = tc.signal; cs.wait_on = tc.wait_on; cs.wait_count = tc.wait_count; cs.timeout = tc.timeout;
+            hipLaunchKernelGGL(crit_panel_kernel, dim3(NB / 16), dim3(512), 0, sm, cs);
+        } else if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
         else HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
         if (!crit_flag) HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
         // Two-level blocking (dense handles): the steps come in groups of `gs` block columns.  A step updates only the
@@ -790,13 +798,18 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         if (grp_last && k > g0) {                                   // operands: block columns g0..k, rows >= k+1
             u.P = panel - (int64_t)(k - g0) * NB; u.Q = u.P; u.K = (k - g0 + 1) * NB;
         }
-        GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1), as 64x64 sub-tiles
-        if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));      // 10 sub-tiles of 32x32
+        GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1)
+        if (crit_regs && uc.K == NB) {                              // (K > 128: the deferred group update, generic kernel)
+            CritStep cs;
+            cs.panel = const_cast<double*>(uc.P); cs.ld = h->mp; cs.inv = nullptr; cs.C = uc.C; cs.ldc = h->mp; cs.done = done;
+            cs.signal = nullptr; cs.wait_on = nullptr; cs.wait_count = 0; cs.timeout = nullptr;
+            hipLaunchKernelGGL(crit_syrk_kernel, dim3(9), dim3(256), 0, sm, cs);
+        } else if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));      // 10 sub-tiles of 32x32
         else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(uc, sm)));
         if (!crit_flag) HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
         if (rem > NB) {
             GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
-            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; tb.timeout = h->d_flags + 2 * (size_t)h->nblk; }   // 4 workgroups in either variant
+            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = crit_regs ? NB / 16 : NB / 32; tb.timeout = h->d_flags + 2 * (size_t)h->nblk; }   // workgroups of the critical panel launch
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
             const int nt = rem / NB;

@@ -57,8 +57,10 @@ struct ipm_handle {
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
     int bulk_variant = 0;                 // 1: BK=32 tiles for the bulk trailing update (measured slower: 2.38 vs 2.26 ms)
-    int crit_variant = 2;                 // critical-path GEMMs: 2 = single-stage register kernels (chol_crit_f64.h), 1 = 32-row
-                                          // tiles of the generic kernel (round 1), 0 = its plain tiles
+    int crit_variant = 1;                 // critical-path GEMMs: 1 = 32-row tiles of the generic kernel, 0 = its plain tiles,
+                                          // 2 = single-stage register kernels (chol_crit_f64.h; measured SLOWER: their
+                                          // fragment-shaped 8-byte loads take 7.4 us, profiles/r02_crit_probe.log)
+    int group_head = -1;                  // leading steps factored in pairs (two-level) before the one-level tail; -1 = auto
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     int last_gs = 1, n_counter_steps = 0, n_event_steps = 0, timeouts_recovered = 0;   // ipm_get_schedule
     bool counted = false;                 // this handle is in g_live
@@ -350,6 +352,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
+    if (const char* e = getenv("IPM_GROUP_HEAD")) h->group_head = atoi(e);
     if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -712,11 +715,30 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         else if (h->nblk >= 96) gs = 4;
         else if (h->nblk >= 48) gs = 3;
     }
+    // Group table.  Uniform groups of gs (>= 48 blocks); below that the HEAD of the factorization -- the steps whose
+    // trailing update (hundreds of tiles, each re-reading and re-writing the trailing matrix) is longer than the pivot
+    // chain -- is factored in pairs and the chain-bound tail one step at a time.
+    std::vector<int> grp_lo(h->nblk), grp_hi(h->nblk);
+    {
+        int head = 0;
+        if (gs == 1 && la && !use_env && h->two_level != 0 && h->group_steps <= 0) {
+            // measured at 4096 x 8192 (32 blocks), factor ms for head = 0 / 4 / 8 / 12 / 16 / 20: 2.158 / 2.157 / 2.182 / 2.183 /
+            // 2.213 / 2.251 -- pairing the head does not pay below 48 blocks either, so the default is 0 (IPM_GROUP_HEAD=n)
+            head = h->group_head >= 0 ? h->group_head : 0;
+            head = std::min(head, h->nblk) & ~1;
+        }
+        for (int k = 0; k < h->nblk; ++k) {
+            if (gs > 1) { grp_lo[k] = (k / gs) * gs; grp_hi[k] = std::min(grp_lo[k] + gs, h->nblk); }
+            else if (k < head) { grp_lo[k] = k & ~1; grp_hi[k] = grp_lo[k] + 2; }
+            else { grp_lo[k] = k; grp_hi[k] = k + 1; }
+        }
+        h->last_gs = (gs == 1 && head > 0) ? 2 : gs;
+    }
     hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
     // device-polled hand-offs only while this is the one live handle on the device (see g_live)
     const bool alone = h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
     const bool fs = la && h->flag_sync != 0 && alone;
-    h->last_gs = gs; h->n_counter_steps = 0; h->n_event_steps = 0;
+    h->n_counter_steps = 0; h->n_event_steps = 0;
     std::vector<unsigned> bulk_wgs(h->nblk, 0u);          // workgroups of the bulk update of each step
     if (la) {
         if (fs) HIP_TRY(h, hipMemsetAsync(h->d_bulk_done, 0, sizeof(unsigned) * 2 * (size_t)h->nblk, sm));
@@ -791,10 +813,10 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         // step of the group applies all of them at once with K = 128 gs -- the group's panels are adjacent block columns
         // of L, i.e. one k-contiguous operand -- so the trailing matrix, whose read-modify-write is what bounds a
         // K = 128 update (16 flop/byte), is streamed once per group instead of once per step.
-        const int g0 = gs > 1 ? (k / gs) * gs : k;
-        const int gend = gs > 1 ? std::min(g0 + gs, h->nblk) : k + 1;      // group = block columns [g0, gend)
-        const bool grp_inner = gs > 1 && k + 1 < gend;              // not the last column of its group: window only
-        const bool grp_last = gs > 1 && !grp_inner;
+        const int g0 = grp_lo[k], gend = grp_hi[k];                  // group = block columns [g0, gend)
+        const bool grouped = gend - g0 > 1;
+        const bool grp_inner = grouped && k + 1 < gend;             // not the last column of its group: window only
+        const bool grp_last = grouped && !grp_inner;
         if (grp_last && k > g0) {                                   // operands: block columns g0..k, rows >= k+1
             u.P = panel - (int64_t)(k - g0) * NB; u.Q = u.P; u.K = (k - g0 + 1) * NB;
         }

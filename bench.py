@@ -42,7 +42,7 @@ def kernel_source_sha():
     version of the kernel is refused (profiles/*_pmc_form_kernel.json carries the sha it was collected with)."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("gemm_nt_f64.h",):
+    for f in ("adat_syrk_f64.h", "gemm_nt_f64.h"):
         with open(os.path.join(ROOT, "interiorpointmethod_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]
@@ -411,7 +411,7 @@ def main():
                                          "the committed PMC pass was collected for another kernel source or size; algorithmic "
                                          "bytes 8mn + 4m^2",
                          "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
-                         "kernel": "gemm_nt_f64_kernel<128,128,16,2,2> (B = A diag(d) A^T)",
+                         "kernel": "adat_syrk_kernel (B = A diag(d) A^T, lower 128x128 tiles, v_mfma_f64_16x16x4_f64)",
                          "flops_per_launch": flops_form, "avg_launch_ms": form_ms},
             "phases_ms_per_step": {"form": form_ms, "factor": phases_all[1] / KB, "trisolve": phases_all[2] / KB,
                                    "other": phases_all[3] / KB, "device_total": dev_ms / K,

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", required=True)
     ap.add_argument("--shape", type=int, nargs=2, default=[4096, 8192])
-    ap.add_argument("--kernel", default="gemm_nt_f64_kernel<128, 128, 16, 2, 2, true>")
+    ap.add_argument("--kernel", default="adat_syrk_kernel")
     args = ap.parse_args()
     import bench
     acc = collections.defaultdict(list)

@@ -64,7 +64,10 @@ __device__ __forceinline__ void crit_signal(const CritStep& g) {
 // rows (the product is IN PLACE), wave w owns the 16 columns 16 w .. 16 w + 15.  inv is lower triangular: column tile w
 // needs k < 16 (w + 1) only, so waves stop their k loop there (chunks of four MFMA steps, wave-uniform).
 __global__ __launch_bounds__(512) void crit_panel_kernel(CritStep g) {
-    if (g.done && *g.done) return;
+    if (g.done && *g.done) {
+        if (g.signal && threadIdx.x == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     crit_wait(g);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -86,7 +86,12 @@ void gemm_nt_f64_kernel(GemmNT g) {
     static_assert((BM * CH) % NT == 0 && (BN * CH) % NT == 0, "tile/threads mismatch");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BK % 4 == 0, "mfma tiling");
 
-    if (g.done && *g.done) return;
+    if (g.done && *g.done) {
+        // a skipped producer still signals: the stop test may flip `done` while a factorization is in flight (it runs
+        // on the residual stream), and a consumer that passed its own check must not spin on a counter nobody bumps
+        if (g.signal && threadIdx.x == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (g.wait_on) {
         if (threadIdx.x == 0) {
             unsigned spins = 0;

@@ -45,6 +45,9 @@ struct ipm_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t stream2 = nullptr;            // bulk stream of the Cholesky look-ahead
+    hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
+    hipEvent_t ev_mid = nullptr, ev_res = nullptr;
+    int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
@@ -357,6 +360,10 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
+    if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
     for (int k = 0; k < h->nblk; ++k) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_diag[k], hipEventDisableTiming));
@@ -385,6 +392,9 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     for (auto& v : {&h->ev_diag, &h->ev_crit, &h->ev_bulk})
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+    if (h->ev_res) (void)hipEventDestroy(h->ev_res);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -628,35 +638,57 @@ static SparseA sparse_view(const ipm_handle* h) {
     return A;
 }
 
-static void launch_gemv_n(ipm_handle* h, const double* v, double sa, double sb, const double* add, double* out) {
+static void launch_gemv_n(ipm_handle* h, const double* v, double sa, double sb, const double* add, double* out,
+                          hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     if (h->sparse) {
-        hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)((h->mp + 15) / 16)), dim3(256), 0, h->stream, sparse_view(h),
+        hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)((h->mp + 15) / 16)), dim3(256), 0, st, sparse_view(h),
                            (int)h->mp, v, sa, sb, add, out, &h->sc->done);
         return;
     }
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)(h->mp / 4)), dim3(256), 0, h->stream, h->A, h->np, (int)h->mp,
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)(h->mp / 4)), dim3(256), 0, st, h->A, h->np, (int)h->mp,
                        (int)h->np, v, sa, sb, add, out, &h->sc->done);
 }
-static void launch_gemv_t(ipm_handle* h, const double* u) {
+static void launch_gemv_t(ipm_handle* h, const double* u, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     if (h->sparse) {
-        hipLaunchKernelGGL(spmv_csc_t_kernel, dim3((unsigned)((h->np + 15) / 16)), dim3(256), 0, h->stream, sparse_view(h),
+        hipLaunchKernelGGL(spmv_csc_t_kernel, dim3((unsigned)((h->np + 15) / 16)), dim3(256), 0, st, sparse_view(h),
                            (int)h->np, u, h->atp, &h->sc->done);
         return;
     }
     dim3 grid((unsigned)((h->np + 511) / 512), (unsigned)h->rc_chunks);
-    hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->A, h->np, h->rows_per_chunk, (int)h->np, u,
+    hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, st, h->A, h->np, h->rows_per_chunk, (int)h->np, u,
                        h->atp, &h->sc->done);
 }
 
 // r_b, r_c, d, predictor v, stop test
-static int enqueue_residuals(ipm_handle* h) {
+static int enqueue_residuals(ipm_handle* h, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     VecArgs a = vec_args(h);
-    launch_gemv_n(h, h->x, 1.0, -1.0, h->b, h->rb);                 // r_b = A x - b
-    launch_gemv_t(h, h->y);                                         // A^T y (partials)
-    hipLaunchKernelGGL(prepare_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
-    hipLaunchKernelGGL(stop_test_kernel, dim3(1), dim3(64), 0, h->stream, a);
+    launch_gemv_n(h, h->x, 1.0, -1.0, h->b, h->rb, st);             // r_b = A x - b
+    launch_gemv_t(h, h->y, st);                                     // A^T y (partials)
+    hipLaunchKernelGGL(prepare_kernel, dim3(h->vblk), dim3(VBLK), 0, st, a);
+    hipLaunchKernelGGL(stop_test_kernel, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
+}
+
+// Residual stream: everything of an iteration that needs (x, y, s) but not the factor -- r_b, r_c, the stop test and the
+// predictor's right-hand side, three of the six passes over A -- runs on its own stream while the pivot chain of the
+// factorization leaves most of the chip idle.  Called from inside enqueue_factor once the chain-bound tail begins (the
+// head of the factorization is bound by its trailing updates, which these HBM passes would only slow down).
+static int enqueue_residual_stream(ipm_handle* h) {
+    HIP_TRY(h, hipEventRecord(h->ev_mid, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_mid, 0));
+    int rc = enqueue_residuals(h, h->stream3);
+    if (rc) return rc;
+    launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1, h->stream3);   // predictor rhs = -r_b - A (d*t)
+    HIP_TRY(h, hipEventRecord(h->ev_res, h->stream3));
+    HIP_TRY(h, hipGetLastError());
+    return IPM_OK;
+}
+static bool overlap_residuals(const ipm_handle* h) {
+    return h->overlap_res != 0 && !h->sparse && h->lookahead != 0 && h->nblk >= 16 && h->profiling < 2;
 }
 
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
@@ -699,7 +731,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 //   main stream : potrf_diag(k) -> [wait bulk(k-1)] -> panel rows of block k+1 -> update of tile (k+1,k+1)
 //   bulk stream : [wait diag(k)] panel rows >= k+2 -> [wait crit(k)] rest of the trailing update
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
-static int enqueue_factor(ipm_handle* h, bool use_env = false) {
+static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1) {
     const int* done = &h->sc->done;
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
@@ -757,6 +789,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false) {
         } else {
             hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         }
+        if (k == mid_step) { int rc_ = enqueue_residual_stream(h); if (rc_) return rc_; }
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
         if (rem <= 0) break;
         if (use_env) {                                              // rows below the envelope are zero and stay zero
@@ -975,9 +1008,9 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out) {
     return IPM_OK;
 }
 
-static int enqueue_predictor(ipm_handle* h, hipEvent_t* ev) {
+static int enqueue_predictor(ipm_handle* h, hipEvent_t* ev, bool have_rhs = false) {
     VecArgs a = vec_args(h);
-    launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);               // rhs = -r_b - A (d*t)
+    if (!have_rhs) launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);   // rhs = -r_b - A (d*t)
     if (ev) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     int rc = enqueue_potrs(h, h->t1, h->dya);
     if (rc) return rc;
@@ -1017,6 +1050,22 @@ static const int EV_PER_IT = 9;
 static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     int rc;
     const bool all = ev && h->profiling >= 2;            // each event record costs the stream ~6 us: level 1 keeps two
+    if (overlap_residuals(h)) {
+        // d = x/s -> formation -> factorization, with the residuals, the stop test and the predictor rhs on the residual
+        // stream under the chain-bound tail of the factorization (from step 3/8 nblk on)
+        VecArgs a = vec_args(h);
+        hipLaunchKernelGGL(scaling_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
+        if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+        if ((rc = enqueue_form(h, h->d))) return rc;
+        if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+        if ((rc = enqueue_factor(h, true, h->nblk * 3 / 8))) return rc;
+        if ((rc = enqueue_group_inverses(h))) return rc;
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));
+        if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;
+        if ((rc = enqueue_corrector(h, nullptr))) return rc;
+        if ((rc = enqueue_update(h))) return rc;
+        return IPM_OK;
+    }
     if (all) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if ((rc = enqueue_residuals(h))) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));

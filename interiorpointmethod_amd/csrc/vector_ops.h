@@ -173,6 +173,14 @@ __global__ __launch_bounds__(VBLK) void prepare_kernel(VecArgs a) {
     }
 }
 
+// d = x / s only (main.py:223): what the formation of A D^2 A^T needs; the full prepare_kernel follows on the residual
+// stream while the factorization runs (ipm_api.hip, enqueue_iteration)
+__global__ __launch_bounds__(VBLK) void scaling_kernel(VecArgs a) {
+    if (a.sc->done) return;
+    const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
+    for (int j = gid; j < a.n; j += gsz) a.d[j] = a.x[j] / a.s[j];
+}
+
 // stop test of check_optimality (main.py:162-173) -- one thread.
 __global__ void stop_test_kernel(VecArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

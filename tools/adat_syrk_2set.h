@@ -1,3 +1,7 @@
+// adat_syrk_2set.h -- A/B copy (tools/syrk_bench.hip only) of a MEASURED AND REJECTED variant of the formation kernel: two
+// staging register sets, inline-asm buffer loads with hand-counted vmcnt, loads 1.75 stages in flight (241 VGPRs).
+// Against the shipped one-set kernel (interiorpointmethod_amd/csrc/adat_syrk_f64.h): 2.016 vs 2.011 ms at 4096 x 8192,
+// 15.67 vs 15.56 ms at 8192 x 16384, 128.3 vs 124.4 ms at 16384 x 32768 (profiles/r02_syrk_ab_3way.log).
 // adat_syrk_f64.h -- the dominant kernel of the dense hot path: B = A diag(d) A^T, lower 128 x 128 tiles,
 // fp64 MFMA (v_mfma_f64_16x16x4_f64) for gfx950.  Replaces the two scipy SpGEMMs of main.py:224 (reference repo).
 //
@@ -13,23 +17,16 @@
 //   * Operands are fetched with buffer loads (one VGPR offset per thread, row and k offsets in SGPRs) instead of
 //     nine 64-bit per-lane pointers: the kernel fits its 256 VGPRs without scratch.
 //
-// Measured on MI355X, standalone, random data (tools/syrk_bench.hip, profiles/r02_syrk_ab_3way.log), against the generic
-// kernel: 2.011 vs 2.075 ms at 4096 x 8192 (68.3 TFLOP/s = 0.87 of the fp64 MFMA peak), 15.56 vs 16.00 ms at 8192 x
-// 16384 (0.90), 124.4 vs 127.4 ms at 16384 x 32768 (70.7 TFLOP/s = 0.90).  A variant with TWO staging register sets
-// (loads 1.75 stages in flight, inline-asm loads, hand-counted vmcnt; tools/adat_syrk_2set.h) was built and rejected:
-// 2.016 / 15.67 / 128.3 ms -- the loads were never the limit.  Inside the solver the same launch takes 2.19 ms: it
-// follows 2.2 ms of the Cholesky pivot chain, and the power manager grants a lower clock after light load
-// (tools/syrk_bench.hip ctx, tools/clock_probe.hip: 2.01 ms back to back, 2.33 ms after 2.8 ms on one workgroup).
-//
 // fp64 MFMA lane maps: see gemm_nt_f64.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "gemm_nt_f64.h"
+#include <type_traits>
+#include "../interiorpointmethod_amd/csrc/adat_syrk_f64.h"
 
 namespace ipm {
 
-struct AdatSyrk {
+struct AdatSyrk2 {
     const double* A; int ld;        // row-major [mp][ld], zero padded; K = 16 nk columns are used
     const double* w;                // scaling d, length >= 16 nk
     double* C; int ldc;             // B, lower tiles written
@@ -41,14 +38,32 @@ struct AdatSyrk {
     double* slab;
 };
 
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f64x2 buf_load_f64x2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return __builtin_bit_cast(f64x2, v);
+
+// Raw buffer resource: 48-bit base, stride 0, num_records in bytes, gfx9 raw-buffer flags.  Out-of-range offsets
+// return zeros instead of faulting.
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+    const uint64_t p = (uint64_t)base;
+    i32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((p >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
 }
 
-__global__ __launch_bounds__(256, 2) void adat_syrk_kernel(AdatSyrk g) {
+// The staging loads are INLINE ASM on purpose: two register sets are in flight at once and the counted waits below
+// (vmcnt(15) ... vmcnt(9)) must leave the younger set alone.  With compiler-tracked loads hipcc merges the in-flight
+// states of the unrolled stage pair at the loop head and falls back to vmcnt(0) in one of the two copies (cdna guide
+// 5.7: loads hidden in inline asm, both queues counted by hand).
+__device__ __forceinline__ f64x2 buf_load2_f64x2(i32x4_t r, int voff, int soff) {
+    f64x2 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(r), "s"(soff) : "memory");
+    return v;
+}
+#define IPM_WAIT_VMCNT(N) do { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__global__ __launch_bounds__(256, 2) void adat_syrk_2set_kernel(AdatSyrk2 g) {
     constexpr int BM = 128, BK = 16, LDT = BK + 2, RSTEP = 32;
     if (g.done && *g.done) return;
 
@@ -77,33 +92,40 @@ __global__ __launch_bounds__(256, 2) void adat_syrk_kernel(AdatSyrk g) {
     const int ti = packed >> 16, tj = packed & 0xffff;
     const int row0 = ti * BM, col0 = tj * BM;
 
-    // buffer resources: base = first row of the operand panel (wave uniform), 128 rows of ld doubles each
+    // buffer resources (raw SGPR quads): base = first row of the operand panel (wave uniform), 128 rows of ld doubles
     const unsigned panel_bytes = (unsigned)BM * (unsigned)g.ld * 8u;
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (int64_t)row0 * g.ld), 0, (int)panel_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (int64_t)col0 * g.ld), 0, (int)panel_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, g.nk * BK * 8, 0x00020000);
+    const i32x4_t rP = make_rsrc(g.A + (int64_t)row0 * g.ld, panel_bytes);
+    const i32x4_t rQ = make_rsrc(g.A + (int64_t)col0 * g.ld, panel_bytes);
+    const i32x4_t rW = make_rsrc(g.w, (unsigned)g.nk * BK * 8u);
 
-    // staging: thread -> 16-byte chunk ch0 of rows r0t + 32 i (i < 4) of both panels
+    // staging: thread -> 16-byte chunk ch0 of rows r0t + 32 i (i < 4) of both panels.  TWO register sets: the loads of
+    // stage l+3 are issued right after the barrier of stage l (into the set whose contents were just written to LDS) and
+    // are written to LDS during k-step 2 of stage l+2, i.e. they are in flight for ~1.75 stages (~7000 cycles): inside
+    // the solver A comes from HBM (~2 us under load), and with one set (0.75 stage in flight) the kernel ran 8 % slower
+    // there than back to back on a cache-warm A.  The loads are issued UNCONDITIONALLY (past the last stage they fall
+    // outside the buffer resource or into the next row and are never stored): a conditional issue makes the compiler
+    // assume the younger set may be absent and wait vmcnt(0) at every LDS write.
     const int ch0 = tid & 7, r0t = tid >> 3;
     const int voff = (r0t * g.ld + ch0 * 2) * 8;
     const int rstep_bytes = RSTEP * g.ld * 8;
-    f64x2 pr[4], qr[4], wr;
-    auto issue_loads = [&](int kt) {
+    f64x2 pr[2][4], qr[2][4], wr[2];
+    auto issue_loads = [&](int set, int kt) {
         const int kb = kt * BK * 8;
-        wr = buf_load_f64x2(rW, ch0 * 16, kb);                 // first: oldest in the vmcnt queue
+        wr[set] = buf_load2_f64x2(rW, ch0 * 16, kb);            // issue order = wait order: w, then (q_i, p_i) pairs
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qr[i] = buf_load_f64x2(rQ, voff, kb + i * rstep_bytes);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pr[i] = buf_load_f64x2(rP, voff, kb + i * rstep_bytes);
+        for (int i = 0; i < 4; ++i) {
+            qr[set][i] = buf_load2_f64x2(rQ, voff, kb + i * rstep_bytes);
+            pr[set][i] = buf_load2_f64x2(rP, voff, kb + i * rstep_bytes);
+        }
     };
     const int st_off = r0t * LDT + ch0 * 2;                    // LDS element offset of this thread's chunk, row group 0
-    auto store_q = [&](int buf, int i) {
-        f64x2 v = qr[i];
-        v.x *= wr.x; v.y *= wr.y;
-        *reinterpret_cast<f64x2*>(Qs + buf * BM * LDT + i * RSTEP * LDT + st_off) = v;
+    auto store_q = [&](int set, int i) {                       // staging set `set` -> LDS buffer `set`
+        f64x2 v = qr[set][i];
+        v.x *= wr[set].x; v.y *= wr[set].y;
+        *reinterpret_cast<f64x2*>(Qs + set * BM * LDT + i * RSTEP * LDT + st_off) = v;
     };
-    auto store_p = [&](int buf, int i) {
-        *reinterpret_cast<f64x2*>(Ps + buf * BM * LDT + i * RSTEP * LDT + st_off) = pr[i];
+    auto store_p = [&](int set, int i) {
+        *reinterpret_cast<f64x2*>(Ps + set * BM * LDT + i * RSTEP * LDT + st_off) = pr[set][i];
     };
 
     const int fr = lane & 15, fk = lane >> 4;
@@ -130,46 +152,69 @@ __global__ __launch_bounds__(256, 2) void adat_syrk_kernel(AdatSyrk g) {
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: stage kbeg into LDS, loads of stage kbeg+1 in flight, first fragments in Fa
-    issue_loads(kbeg);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) store_q(kbeg & 1, i);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) store_p(kbeg & 1, i);
-    __syncthreads();
-    if (kbeg + 1 < kend) issue_loads(kbeg + 1);
-    read_frags(0, kbeg & 1, 0);
-
-    for (int kt = kbeg; kt < kend; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < kend;
-        read_frags(1, buf, 1);
+    // One K stage.  P (compile time) = parity of the local stage index l = kt - kbeg: stage l lives in LDS buffer P, the
+    // operands of stage l+1 wait in staging set P^1 (written to LDS buffer P^1 here), those of stage l+2 are in flight
+    // in set P, and set P^1 is refilled with stage l+3 after the barrier.
+    const int nst = kend - kbeg;
+    auto stage = [&](auto Ptag, int l) {
+        constexpr int P = decltype(Ptag)::value;
+        const bool more = l + 1 < nst;
+        read_frags(1, P, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma16(0);                                              // k-step 0
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(0, buf, 2);
+        read_frags(0, P, 2);
         __builtin_amdgcn_sched_barrier(0);
         mfma16(1);                                              // k-step 1
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(1, buf, 3);
+        read_frags(1, P, 3);
         __builtin_amdgcn_sched_barrier(0);
-        // k-step 2, with the next stage's operands written to the other LDS buffer between its MFMA rows (the global
-        // loads were issued three k-steps ago; their waits sit behind 4 MFMAs each instead of in front of all 16)
+        // k-step 2, with the next stage's operands written to the other LDS buffer between its MFMA rows
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
-            if (more) { store_q(buf ^ 1, i); store_p(buf ^ 1, i); }
+            // set P^1 (older): w, q0, p0, ..., q3, p3, then the 9 loads of set P: row i needs everything up to p_i
+            if (i == 0) IPM_WAIT_VMCNT(15); else if (i == 1) IPM_WAIT_VMCNT(13); else if (i == 2) IPM_WAIT_VMCNT(11); else IPM_WAIT_VMCNT(9);
+            if (more) { store_q(P ^ 1, i); store_p(P ^ 1, i); }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                        // writes of stage kt+1 visible; reads of stage kt issued
-        if (kt + 2 < kend) issue_loads(kt + 2);
-        if (more) read_frags(0, buf ^ 1, 0);
+        // LDS only: the barrier must not drain the global loads in flight (raw s_barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // writes of stage l+1 visible; reads of stage l issued
+        __builtin_amdgcn_sched_barrier(0);
+        issue_loads(P ^ 1, kbeg + l + 3);
+        if (more) read_frags(0, P ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         mfma16(1);                                              // k-step 3
         __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: stage 0 into LDS buffer 0, loads of stage 1 in flight in set 1, first fragments in Fa
+    issue_loads(0, kbeg);
+    issue_loads(1, kbeg + 1);
+    IPM_WAIT_VMCNT(9);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_q(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_p(0, i);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_loads(0, kbeg + 2);
+    read_frags(0, 0, 0);
+    // (exits only, no conditional call: the back edge must always come from an odd stage, otherwise the compiler's
+    // vmcnt bookkeeping merges two different in-flight states at the loop head and falls back to vmcnt(0))
+    for (int l = 0;; l += 2) {
+        stage(std::integral_constant<int, 0>{}, l);
+        if (l + 1 >= nst) break;
+        stage(std::integral_constant<int, 1>{}, l + 1);
+        if (l + 2 >= nst) break;
     }
+    // the run-ahead loads past the last stage are never consumed, so their registers are dead to the compiler: drain
+    // them before anything else may be allocated there
+    IPM_WAIT_VMCNT(0);
 
     // ---- epilogue: D[row=(l>>4)+4q][col=l&15]
     if (slab_out) {                                             // split-K partial: raw tile, summed later
@@ -199,12 +244,12 @@ __global__ __launch_bounds__(256, 2) void adat_syrk_kernel(AdatSyrk g) {
 
 // B = A diag(w) A^T, lower 128 x 128 tiles in `tile_order`; tiles beyond a multiple of `slots` resident workgroups are
 // split along K into slabs and summed in fixed order by splitk_reduce_kernel (same policy as launch_gemm_nt).
-inline hipError_t launch_adat_syrk(const double* A, int64_t ld, const double* w, double* C, int64_t ldc, int M, int K,
+inline hipError_t launch_adat_syrk_2set(const double* A, int64_t ld, const double* w, double* C, int64_t ldc, int M, int K,
                                    int unit_diag_from, const int* done, const int* tile_order, hipStream_t stream,
                                    double* slab, int slots = 512) {
     const int nt = M / 128, tiles = nt * (nt + 1) / 2, nk = K / 16;
     if (tiles <= 0 || nk <= 0) return hipSuccess;
-    AdatSyrk g;
+    AdatSyrk2 g;
     g.A = A; g.ld = (int)ld; g.w = w; g.C = C; g.ldc = (int)ldc; g.nk = nk; g.unit_diag_from = unit_diag_from;
     g.done = done; g.tile_order = tile_order;
     g.n_direct = tiles; g.split_p = 1; g.chunk_stages = nk; g.slab = nullptr;
@@ -223,7 +268,7 @@ inline hipError_t launch_adat_syrk(const double* A, int64_t ld, const double* w,
             }
         }
     }
-    hipLaunchKernelGGL(adat_syrk_kernel, dim3(grid), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(adat_syrk_2set_kernel, dim3(grid), dim3(256), 0, stream, g);
     if (g.slab) {
         GemmNT r;
         memset(&r, 0, sizeof r);

@@ -1,6 +1,7 @@
 // syrk_bench.hip -- A/B timing of the dominant kernel (B = A diag(d) A^T) in ONE process, interleaved rounds
 // (cdna guide 5.4 rule 24): the generic gemm_nt_f64_kernel<128,128,16,2,2,true> against adat_syrk_kernel, on
-// random data, with a bit-for-bit comparison of the two results.
+// random data, with a bit-for-bit comparison of the two results; third arm: the rejected two-register-set variant
+// (tools/adat_syrk_2set.h).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/syrk_bench tools/syrk_bench.hip
 //   tools/bin/syrk_bench [m n rounds]
 #include <hip/hip_runtime.h>
@@ -11,6 +12,7 @@
 #include <algorithm>
 #include "../interiorpointmethod_amd/csrc/gemm_nt_f64.h"
 #include "../interiorpointmethod_amd/csrc/adat_syrk_f64.h"
+#include "adat_syrk_2set.h"
 using namespace ipm;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -61,6 +63,7 @@ int main(int argc, char** argv) {
         CK((launch_gemm_nt<128, 128, 16, 2, 2>(g, st, slab, 512)));
     };
     auto run_new = [&]() { CK(launch_adat_syrk(A, n, d, B1, m, m, n, -1, nullptr, ord, st, slab, 512)); };
+    auto run_one = [&]() { CK(launch_adat_syrk_2set(A, n, d, B1, m, m, n, -1, nullptr, ord, st, slab, 512)); };
     run_old(); run_new(); CK(hipStreamSynchronize(st));
     std::vector<double> h0((size_t)m * m), h1((size_t)m * m);
     CK(hipMemcpy(h0.data(), B0, h0.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), B1, h1.size() * 8, hipMemcpyDeviceToHost));
@@ -71,7 +74,7 @@ int main(int argc, char** argv) {
     }
     printf("compare old vs new: %zu differing entries, max |diff| %.3e (B[1][0]=%.6f)\n", ndiff, maxd, h0[(size_t)m]);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    std::vector<float> t_old, t_new;
+    std::vector<float> t_old, t_new, t_one;
     const int reps = 5;
     for (int r = 0; r < rounds; ++r) {
         float ms;
@@ -79,6 +82,8 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1)); t_old.push_back(ms / reps);
         CK(hipEventRecord(e0, st)); for (int i = 0; i < reps; ++i) run_new(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); t_new.push_back(ms / reps);
+        CK(hipEventRecord(e0, st)); for (int i = 0; i < reps; ++i) run_one(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); t_one.push_back(ms / reps);
     }
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     if (argc > 4) {      // context probes (new kernel only): time ONE formation after (a) nothing, (b) an idle gap, (c) a cache flush, (d) both
@@ -100,6 +105,7 @@ int main(int argc, char** argv) {
     }
     auto mn = [](std::vector<float> v) { return *std::min_element(v.begin(), v.end()); };
     const double fl = (double)m * m * n;
+    printf("m=%d n=%d  two-set variant (rejected): median %.4f ms (%.1f TF) min %.4f\n", m, n, med(t_one), fl / med(t_one) * 1e-9, mn(t_one));
     printf("m=%d n=%d  generic: median %.4f ms (%.1f TF) min %.4f | adat_syrk: median %.4f ms (%.1f TF, %.3f of 78.6) min %.4f\n", m, n,
            med(t_old), fl / med(t_old) * 1e-9, mn(t_old), med(t_new), fl / med(t_new) * 1e-9, fl / med(t_new) * 1e-9 / 78.6, mn(t_new));
     return 0;

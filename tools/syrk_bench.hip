@@ -86,7 +86,28 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1)); t_one.push_back(ms / reps);
     }
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-    if (argc > 4) {      // context probes (new kernel only): time ONE formation after (a) nothing, (b) an idle gap, (c) a cache flush, (d) both
+    if (argc > 4 && !strcmp(argv[4], "upd")) {
+        // the bulk trailing update of a Cholesky step in isolation: B(i,j) -= L(i,k) L(j,k)^T on the lower tiles below block
+        // row/column kb, K = 128 (what enqueue_factor launches on the bulk stream), for a few step indices
+        for (int kb : {0, 1, 4, 9, 15, 23}) {
+            const int rem = m - (kb + 1) * 128;
+            if (rem <= 128) continue;
+            GemmNT u; memset(&u, 0, sizeof u);
+            u.batch = 1; u.batch2 = 1; u.unit_diag_from = -1;
+            double* panel = B0 + (size_t)(kb + 1) * 128 * m + (size_t)kb * 128;
+            u.P = panel; u.ldp = m; u.Q = panel; u.ldq = m; u.C = B0 + (size_t)(kb + 1) * 128 * (m + 1); u.ldc = m;
+            u.M = rem; u.N = rem; u.K = 128; u.alpha = -1e-9; u.beta = 1.0; u.lower = 1;
+            std::vector<float> t;
+            for (int r = 0; r < 7; ++r) {
+                float ms; CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 10; ++i) CK((launch_gemm_nt<128, 128, 16, 2, 2>(u, st, nullptr, 512, 1)));
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms * 100.f);
+            }
+            const int nt = rem / 128, tiles = nt * (nt + 1) / 2 - 1;
+            printf("  trailing update after step %2d: %4d tiles, K = 128: %.1f us per launch (median of 7 x 10)  = %.1f TFLOP/s\n", kb, tiles, med(t),
+                   2.0 * tiles * 128.0 * 128.0 * 128.0 / (med(t) * 1e-6) * 1e-12);
+        }
+    } else if (argc > 4) {      // context probes (new kernel only): time ONE formation after (a) nothing, (b) an idle gap, (c) a cache flush, (d) both
         double *f0, *f1; const size_t fn = (size_t)48 << 20;     // 2 x 384 MB
         CK(hipMalloc(&f0, fn * 8)); CK(hipMalloc(&f1, fn * 8)); CK(hipMemset(f0, 0, fn * 8));
         const char* names[4] = {"back to back", "after 2.8 ms on one workgroup", "after 0.77 GB of other traffic", "after both"};

@@ -48,6 +48,7 @@ struct ipm_handle {
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
     hipEvent_t ev_mid = nullptr, ev_res = nullptr;
     int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
+    int residual_step = -1;                   // factorization step at which the residual stream starts (-1: 13/16 nblk; IPM_RESIDUAL_STEP)
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
@@ -364,6 +365,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
     if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
+    if (const char* e = getenv("IPM_RESIDUAL_STEP")) h->residual_step = atoi(e);
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
     for (int k = 0; k < h->nblk; ++k) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_diag[k], hipEventDisableTiming));
@@ -1052,13 +1054,16 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     const bool all = ev && h->profiling >= 2;            // each event record costs the stream ~6 us: level 1 keeps two
     if (overlap_residuals(h)) {
         // d = x/s -> formation -> factorization, with the residuals, the stop test and the predictor rhs on the residual
-        // stream under the chain-bound tail of the factorization (from step 3/8 nblk on)
+        // stream under the chain-bound tail of the factorization
         VecArgs a = vec_args(h);
         hipLaunchKernelGGL(scaling_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
         if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         if ((rc = enqueue_form(h, h->d))) return rc;
         if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-        if ((rc = enqueue_factor(h, true, h->nblk * 3 / 8))) return rc;
+        // start late in the chain-bound tail: the three passes need ~0.2 ms, six steps of the chain.  Measured at 32 blocks
+        // (it/s for a start at step 0 / 4 / 12 / 20 / 26 / 30): 199.5 / 199.6 / 200.6 / 201.0 / 203.1 / 200.5
+        const int rstep = h->residual_step >= 0 ? std::min(h->residual_step, h->nblk - 1) : h->nblk * 13 / 16;
+        if ((rc = enqueue_factor(h, true, rstep))) return rc;
         if ((rc = enqueue_group_inverses(h))) return rc;
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));
         if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;

@@ -46,7 +46,8 @@ struct ipm_handle {
     bool own_stream = false;
     hipStream_t stream2 = nullptr;            // bulk stream of the Cholesky look-ahead
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
-    hipEvent_t ev_mid = nullptr, ev_res = nullptr;
+    hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr;
+    int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
     int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
     int residual_step = -1;                   // factorization step at which the residual stream starts (-1: 13/16 nblk; IPM_RESIDUAL_STEP)
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
@@ -364,6 +365,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
+    if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
     if (const char* e = getenv("IPM_RESIDUAL_STEP")) h->residual_step = atoi(e);
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
@@ -397,6 +400,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->ev_res) (void)hipEventDestroy(h->ev_res);
+    if (h->ev_grp) (void)hipEventDestroy(h->ev_grp);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -733,7 +737,8 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 //   main stream : potrf_diag(k) -> [wait bulk(k-1)] -> panel rows of block k+1 -> update of tile (k+1,k+1)
 //   bulk stream : [wait diag(k)] panel rows >= k+2 -> [wait crit(k)] rest of the trailing update
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
-static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1) {
+static int enqueue_group_inverses(ipm_handle* h, int g0, int g1, hipStream_t st);
+static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1, int ginv_step = -1) {
     const int* done = &h->sc->done;
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
@@ -790,6 +795,15 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         } else {
             hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
+        }
+        if (k == ginv_step) {
+            // blocks 0 .. k are final (the diagonal block k was just factored, every panel block left of it in these rows is
+            // ordered before it through the look-ahead hand-offs): the inverses of the complete 1024-row groups go to the
+            // residual stream, only the last group's is left for after the factorization
+            HIP_TRY(h, hipEventRecord(h->ev_grp, sm));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
+            int rc_ = enqueue_group_inverses(h, 0, (k + 1) / GS, h->stream3);
+            if (rc_) return rc_;
         }
         if (k == mid_step) { int rc_ = enqueue_residual_stream(h); if (rc_) return rc_; }
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
@@ -904,35 +918,41 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
 // X_g, XT_g = inv of every 1024 x 1024 diagonal group of the factor and its transpose (trsv_grouped.h):
 // recursive doubling 128 -> 256 -> 512 -> 1024, three GEMMs per level batched over (pairs in a group,
 // groups).  After enqueue_factor, on the main stream.
-static int enqueue_group_inverses(ipm_handle* h) {
+static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStream_t st = nullptr) {
     if (!h->grouped_trsv) return IPM_OK;
-    const int nG = h->nblk / GS;
+    if (g1 < 0) g1 = h->nblk / GS;
+    if (!st) st = h->stream;
+    const int nG = g1 - g0;                               // groups [g0, g1)
+    if (nG <= 0) return IPM_OK;
     const int* done = &h->sc->done;
-    hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, h->nblk), dim3(32, 8), 0, h->stream, h->invD, h->gXT, h->gX, 0, done);
+    hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, nG * GS), dim3(32, 8), 0, st, h->invD, h->gXT, h->gX, g0 * GS, done);
+    const int64_t gXs = (int64_t)GR * GR, gL = (int64_t)GR * (h->mp + 1), gSs = (int64_t)512 * 512;   // group strides in X/XT, L, S
+    double* gXT = h->gXT + g0 * gXs; double* gX = h->gX + g0 * gXs; double* gS = h->gS + g0 * gSs;
+    const double* Lg = h->B + g0 * gL;
     for (int hs = 128; hs < GR; hs *= 2) {
         const int np = GR / (2 * hs);                     // pairs per group
         const bool small = h->ginv_variant == 1 || (h->ginv_variant == 2 && hs >= 256);   // 32 x 32 tiles: 4x the workgroups
         GemmNT t = gemm_defaults();
         t.tile_order = nullptr; t.w = nullptr; t.done = done; t.lower = 0; t.unit_diag_from = -1;
         t.M = hs; t.N = hs; t.K = hs; t.beta = 0.0; t.batch = np; t.batch2 = nG;
-        const int64_t pX = (int64_t)2 * hs * (GR + 1), gXs = (int64_t)GR * GR;        // pair / group strides in X, XT
-        const int64_t pL = (int64_t)2 * hs * (h->mp + 1), gL = (int64_t)GR * (h->mp + 1);
-        const int64_t pS = (int64_t)hs * hs, gSs = (int64_t)512 * 512;
+        const int64_t pX = (int64_t)2 * hs * (GR + 1);                                 // pair strides in X, XT
+        const int64_t pL = (int64_t)2 * hs * (h->mp + 1);
+        const int64_t pS = (int64_t)hs * hs;
         GemmNT a = t;                                     // S = XT11 * L21^T
-        a.P = h->gXT; a.ldp = GR; a.sP = pX; a.sP2 = gXs;
-        a.Q = h->B + (int64_t)hs * h->mp; a.ldq = h->mp; a.sQ = pL; a.sQ2 = gL;
-        a.C = h->gS; a.ldc = hs; a.sC = pS; a.sC2 = gSs; a.alpha = 1.0;
-        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(a, h->stream))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(a, h->stream)));
+        a.P = gXT; a.ldp = GR; a.sP = pX; a.sP2 = gXs;
+        a.Q = Lg + (int64_t)hs * h->mp; a.ldq = h->mp; a.sQ = pL; a.sQ2 = gL;
+        a.C = gS; a.ldc = hs; a.sC = pS; a.sC2 = gSs; a.alpha = 1.0;
+        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(a, st))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(a, st)));
         GemmNT b = t;                                     // X21 = -X22 * S^T
-        b.P = h->gX + (int64_t)hs * GR + hs; b.ldp = GR; b.sP = pX; b.sP2 = gXs;
-        b.Q = h->gS; b.ldq = hs; b.sQ = pS; b.sQ2 = gSs;
-        b.C = h->gX + (int64_t)hs * GR; b.ldc = GR; b.sC = pX; b.sC2 = gXs; b.alpha = -1.0;
-        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(b, h->stream))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(b, h->stream)));
+        b.P = gX + (int64_t)hs * GR + hs; b.ldp = GR; b.sP = pX; b.sP2 = gXs;
+        b.Q = gS; b.ldq = hs; b.sQ = pS; b.sQ2 = gSs;
+        b.C = gX + (int64_t)hs * GR; b.ldc = GR; b.sC = pX; b.sC2 = gXs; b.alpha = -1.0;
+        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(b, st))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(b, st)));
         GemmNT c = t;                                     // XT12 = -S * X22^T
-        c.P = h->gS; c.ldp = hs; c.sP = pS; c.sP2 = gSs;
-        c.Q = h->gX + (int64_t)hs * GR + hs; c.ldq = GR; c.sQ = pX; c.sQ2 = gXs;
-        c.C = h->gXT + hs; c.ldc = GR; c.sC = pX; c.sC2 = gXs; c.alpha = -1.0;
-        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(c, h->stream))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(c, h->stream)));
+        c.P = gS; c.ldp = hs; c.sP = pS; c.sP2 = gSs;
+        c.Q = gX + (int64_t)hs * GR + hs; c.ldq = GR; c.sQ = pX; c.sQ2 = gXs;
+        c.C = gXT + hs; c.ldc = GR; c.sC = pX; c.sC2 = gXs; c.alpha = -1.0;
+        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(c, st))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(c, st)));
     }
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
@@ -1063,8 +1083,10 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         // start late in the chain-bound tail: the three passes need ~0.2 ms, six steps of the chain.  Measured at 32 blocks
         // (it/s for a start at step 0 / 4 / 12 / 20 / 26 / 30): 199.5 / 199.6 / 200.6 / 201.0 / 203.1 / 200.5
         const int rstep = h->residual_step >= 0 ? std::min(h->residual_step, h->nblk - 1) : h->nblk * 13 / 16;
-        if ((rc = enqueue_factor(h, true, rstep))) return rc;
-        if ((rc = enqueue_group_inverses(h))) return rc;
+        const int nG = h->grouped_trsv ? h->nblk / GS : 0;
+        const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * GS - 1 < rstep) ? (nG - 1) * GS - 1 : -1;
+        if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
+        if ((rc = enqueue_group_inverses(h, gstep >= 0 ? nG - 1 : 0, nG, nullptr))) return rc;
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));
         if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;
         if ((rc = enqueue_corrector(h, nullptr))) return rc;

@@ -72,6 +72,9 @@ struct ipm_handle {
     // fused single-workgroup path for small sparse LPs (small_lp.h): product list of B's lower entries, own allocation
     bool small = false;
     int fused_small = 1;                  // IPM_FUSED_SMALL=0: always the multi-kernel path
+    bool list_form = false;               // sparse handle, <= 4096 padded rows: B from the product list (adat_list_kernel)
+    int list_form_opt = 1;                // IPM_LIST_FORM=0: one workgroup per row of B (adat_sparse_kernel)
+    int *ls_bi = nullptr, *ls_bk = nullptr;
     int sm_nb = 0;
     int *sm_bptr = nullptr, *sm_bcol = nullptr;
     unsigned short *sm_bi = nullptr, *sm_bk = nullptr;
@@ -359,6 +362,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
     if (const char* e = getenv("IPM_GROUP_HEAD")) h->group_head = atoi(e);
     if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
+    if (const char* e = getenv("IPM_LIST_FORM")) h->list_form_opt = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -412,7 +416,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->gX) (void)hipFree(h->gX);
     if (h->gS) (void)hipFree(h->gS);
     if (h->gPart) (void)hipFree(h->gPart);
-    for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef})
+    for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk})
         if (p) (void)hipFree(p);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -499,54 +503,73 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
             h->use_env = h->envelope != 0 && work < 0.8 * dense;         // only when it actually removes work
         }
         h->nnz = nz; h->haveA = true; h->predictor_valid = false;
-        h->small = false;
-        if (h->fused_small && h->m <= SMALL_MAX_M) {
-            // product list of the fused small-LP kernel: lower entry (i, k) of B = A diag(d) A^T is
-            // sum_t coef[t] d[col[t]] over the columns that rows i and k share (coef = a_ij a_kj); entries ordered
-            // by (i, k), terms by column: a fixed summation order
+        h->small = false; h->list_form = false;
+        {
+            // Product list: lower entry (i, k) of B = A diag(d) A^T is sum_t coef[t] d[col[t]] over the columns that rows
+            // i and k share (coef = a_ij a_kj) -- a sparse matrix-vector product with d.  Entries ordered by (i, k), terms
+            // by column: a fixed summation order.  Used by the fused small-LP kernel (m <= 128) and, for sparse handles up
+            // to 4096 padded rows, by adat_list_kernel (one thread per entry instead of one workgroup per row of B walking
+            // its nonzeros one dependent load at a time).
             size_t terms = 0;
             for (int64_t j = 0; j < h->n; ++j) { const size_t c = (size_t)(cp[j + 1] - cp[j]); terms += c * (c + 1) / 2; }
-            if (terms <= ((size_t)1 << 22)) {
+            const bool want_small = h->fused_small && h->m <= SMALL_MAX_M && terms <= ((size_t)1 << 22);
+            const bool want_list = h->list_form_opt && h->m > SMALL_MAX_M && h->mp <= 4096 && terms <= ((size_t)1 << 24);
+            if (want_small || want_list) {
                 const int M = (int)h->m;
-                std::vector<int> cnt((size_t)M * M, 0);
-                for (int64_t j = 0; j < h->n; ++j)
-                    for (int p = cp[j]; p < cp[j + 1]; ++p)
-                        for (int q = cp[j]; q <= p; ++q) cnt[(size_t)ri[p] * M + ri[q]]++;          // ri sorted: ri[p] >= ri[q]
-                std::vector<int> bptr(1, 0), slot((size_t)M * M, -1);
-                std::vector<unsigned short> bi, bk;
-                for (int i = 0; i < M; ++i)
-                    for (int k = 0; k <= i; ++k)
-                        if (cnt[(size_t)i * M + k] > 0 || i == k) {                                  // the diagonal always exists
-                            slot[(size_t)i * M + k] = (int)bi.size();
-                            bi.push_back((unsigned short)i); bk.push_back((unsigned short)k);
-                            bptr.push_back(bptr.back() + cnt[(size_t)i * M + k]);
+                std::vector<int> bptr(1, 0), bi, bk, mark((size_t)M, -1), cntk((size_t)M, 0), startk((size_t)M, 0), touched;
+                std::vector<int> bcol(terms ? terms : 1);
+                std::vector<double> bcoef(terms ? terms : 1);
+                for (int i = 0; i < M; ++i) {
+                    touched.clear();
+                    mark[i] = i; cntk[i] = 0; touched.push_back(i);                       // the diagonal entry always exists
+                    for (int p = rp[i]; p < rp[i + 1]; ++p) {
+                        const int j = ci[p];
+                        for (int q = cp[j]; q < cp[j + 1] && ri[q] <= i; ++q) {            // rows sorted within a column
+                            const int k = ri[q];
+                            if (mark[k] != i) { mark[k] = i; cntk[k] = 0; touched.push_back(k); }
+                            ++cntk[k];
                         }
-                std::vector<int> fill(bptr.begin(), bptr.end() - 1), bcol((size_t)bptr.back());
-                std::vector<double> bcoef((size_t)bptr.back());
-                for (int64_t j = 0; j < h->n; ++j)                                                   // j ascending: terms of an entry sorted by column
-                    for (int p = cp[j]; p < cp[j + 1]; ++p)
-                        for (int q = cp[j]; q <= p; ++q) {
-                            const int e = slot[(size_t)ri[p] * M + ri[q]];
-                            const int t = fill[e]++;
-                            bcol[t] = (int)j; bcoef[t] = cv[p] * cv[q];
+                    }
+                    std::sort(touched.begin(), touched.end());
+                    for (int k : touched) {
+                        startk[k] = bptr.back();
+                        bi.push_back(i); bk.push_back(k);
+                        bptr.push_back(bptr.back() + cntk[k]);
+                    }
+                    for (int p = rp[i]; p < rp[i + 1]; ++p) {                              // columns ascending within the row
+                        const int j = ci[p];
+                        const double aij = rv[p];
+                        for (int q = cp[j]; q < cp[j + 1] && ri[q] <= i; ++q) {
+                            const int t = startk[ri[q]]++;
+                            bcol[t] = j; bcoef[t] = aij * cv[q];
                         }
-                for (void** p : {(void**)&h->sm_bptr, (void**)&h->sm_bcol, (void**)&h->sm_bi, (void**)&h->sm_bk, (void**)&h->sm_bcoef})
+                    }
+                }
+                for (void** p : {(void**)&h->sm_bptr, (void**)&h->sm_bcol, (void**)&h->sm_bi, (void**)&h->sm_bk, (void**)&h->sm_bcoef,
+                                 (void**)&h->ls_bi, (void**)&h->ls_bk})
                     if (*p) { (void)hipFree(*p); *p = nullptr; }
                 h->sm_nb = (int)bi.size();
-                const size_t nt_ = bcol.size() ? bcol.size() : 1;
+                const size_t nt_ = bcol.size();
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bptr, sizeof(int) * bptr.size()));
-                HIP_TRY(h, hipMalloc((void**)&h->sm_bi, sizeof(unsigned short) * bi.size()));
-                HIP_TRY(h, hipMalloc((void**)&h->sm_bk, sizeof(unsigned short) * bk.size()));
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bcol, sizeof(int) * nt_));
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bcoef, sizeof(double) * nt_));
                 HIP_TRY(h, hipMemcpy(h->sm_bptr, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice));
-                HIP_TRY(h, hipMemcpy(h->sm_bi, bi.data(), sizeof(unsigned short) * bi.size(), hipMemcpyHostToDevice));
-                HIP_TRY(h, hipMemcpy(h->sm_bk, bk.data(), sizeof(unsigned short) * bk.size(), hipMemcpyHostToDevice));
-                if (!bcol.empty()) {
-                    HIP_TRY(h, hipMemcpy(h->sm_bcol, bcol.data(), sizeof(int) * bcol.size(), hipMemcpyHostToDevice));
-                    HIP_TRY(h, hipMemcpy(h->sm_bcoef, bcoef.data(), sizeof(double) * bcoef.size(), hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpy(h->sm_bcol, bcol.data(), sizeof(int) * nt_, hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpy(h->sm_bcoef, bcoef.data(), sizeof(double) * nt_, hipMemcpyHostToDevice));
+                if (want_small) {
+                    std::vector<unsigned short> si(bi.begin(), bi.end()), sk(bk.begin(), bk.end());
+                    HIP_TRY(h, hipMalloc((void**)&h->sm_bi, sizeof(unsigned short) * si.size()));
+                    HIP_TRY(h, hipMalloc((void**)&h->sm_bk, sizeof(unsigned short) * sk.size()));
+                    HIP_TRY(h, hipMemcpy(h->sm_bi, si.data(), sizeof(unsigned short) * si.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpy(h->sm_bk, sk.data(), sizeof(unsigned short) * sk.size(), hipMemcpyHostToDevice));
+                    h->small = true;
+                } else {
+                    HIP_TRY(h, hipMalloc((void**)&h->ls_bi, sizeof(int) * bi.size()));
+                    HIP_TRY(h, hipMalloc((void**)&h->ls_bk, sizeof(int) * bk.size()));
+                    HIP_TRY(h, hipMemcpy(h->ls_bi, bi.data(), sizeof(int) * bi.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpy(h->ls_bk, bk.data(), sizeof(int) * bk.size(), hipMemcpyHostToDevice));
+                    h->list_form = true;
                 }
-                h->small = true;
             }
         }
         return IPM_OK;
@@ -699,6 +722,14 @@ static bool overlap_residuals(const ipm_handle* h) {
 
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
 static int enqueue_form(ipm_handle* h, const double* d) {
+    if (h->sparse && h->list_form) {
+        HIP_TRY(h, hipMemsetAsync(h->B, 0, sizeof(double) * h->mp * h->mp, h->stream));
+        const int work = h->sm_nb + (int)(h->mp - h->m);
+        hipLaunchKernelGGL(adat_list_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, h->sm_bptr, h->ls_bi, h->ls_bk,
+                           h->sm_bcol, h->sm_bcoef, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done);
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
     if (h->sparse) {
         if (h->mp <= SP_LDS_MAX_MP) {          // dynamic-LDS attribute set per device in ipm_create
             hipLaunchKernelGGL(adat_sparse_kernel, dim3((unsigned)h->mp), dim3(256), (size_t)h->mp * sizeof(double), h->stream,

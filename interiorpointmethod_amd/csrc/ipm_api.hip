@@ -75,6 +75,7 @@ struct ipm_handle {
     bool list_form = false;               // sparse handle, <= 4096 padded rows: B from the product list (adat_list_kernel)
     int list_form_opt = 1;                // IPM_LIST_FORM=0: one workgroup per row of B (adat_sparse_kernel)
     int *ls_bi = nullptr, *ls_bk = nullptr;
+    double* ls_bak = nullptr;             // list path: sm_bcoef holds a_ij, ls_bak a_kj (the products are formed on the device)
     int sm_nb = 0;
     int *sm_bptr = nullptr, *sm_bcol = nullptr;
     unsigned short *sm_bi = nullptr, *sm_bk = nullptr;
@@ -416,7 +417,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->gX) (void)hipFree(h->gX);
     if (h->gS) (void)hipFree(h->gS);
     if (h->gPart) (void)hipFree(h->gPart);
-    for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk})
+    for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
         if (p) (void)hipFree(p);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -517,14 +518,19 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
             if (want_small || want_list) {
                 const int M = (int)h->m;
                 std::vector<int> bptr(1, 0), bi, bk, mark((size_t)M, -1), cntk((size_t)M, 0), startk((size_t)M, 0), touched;
-                std::vector<int> bcol(terms ? terms : 1);
-                std::vector<double> bcoef(terms ? terms : 1);
+                // list path: entries up to the end of row i's 16 x 16 diagonal tile (potrf_diag reads those tiles whole), each
+                // computed from its own row's point of view -- exactly the values, products and order of adat_sparse_kernel
+                const int hi_mask = want_small ? 0 : 15;
+                std::vector<int> bcol;
+                std::vector<double> bai, bak;
+                bcol.reserve(terms + 16 * (size_t)M); bai.reserve(terms + 16 * (size_t)M); bak.reserve(terms + 16 * (size_t)M);
                 for (int i = 0; i < M; ++i) {
+                    const int hi = std::min(i | hi_mask, M - 1);
                     touched.clear();
                     mark[i] = i; cntk[i] = 0; touched.push_back(i);                       // the diagonal entry always exists
                     for (int p = rp[i]; p < rp[i + 1]; ++p) {
                         const int j = ci[p];
-                        for (int q = cp[j]; q < cp[j + 1] && ri[q] <= i; ++q) {            // rows sorted within a column
+                        for (int q = cp[j]; q < cp[j + 1] && ri[q] <= hi; ++q) {           // rows sorted within a column
                             const int k = ri[q];
                             if (mark[k] != i) { mark[k] = i; cntk[k] = 0; touched.push_back(k); }
                             ++cntk[k];
@@ -536,17 +542,21 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
                         bi.push_back(i); bk.push_back(k);
                         bptr.push_back(bptr.back() + cntk[k]);
                     }
+                    bcol.resize((size_t)bptr.back()); bai.resize((size_t)bptr.back()); bak.resize((size_t)bptr.back());
                     for (int p = rp[i]; p < rp[i + 1]; ++p) {                              // columns ascending within the row
                         const int j = ci[p];
                         const double aij = rv[p];
-                        for (int q = cp[j]; q < cp[j + 1] && ri[q] <= i; ++q) {
+                        for (int q = cp[j]; q < cp[j + 1] && ri[q] <= hi; ++q) {
                             const int t = startk[ri[q]]++;
-                            bcol[t] = j; bcoef[t] = aij * cv[q];
+                            bcol[t] = j; bai[t] = aij; bak[t] = cv[q];
                         }
                     }
                 }
+                if (bcol.empty()) { bcol.push_back(0); bai.push_back(0.0); bak.push_back(0.0); }
+                std::vector<double> bcoef(bcol.size());
+                for (size_t t = 0; t < bcol.size(); ++t) bcoef[t] = bai[t] * bak[t];
                 for (void** p : {(void**)&h->sm_bptr, (void**)&h->sm_bcol, (void**)&h->sm_bi, (void**)&h->sm_bk, (void**)&h->sm_bcoef,
-                                 (void**)&h->ls_bi, (void**)&h->ls_bk})
+                                 (void**)&h->ls_bi, (void**)&h->ls_bk, (void**)&h->ls_bak})
                     if (*p) { (void)hipFree(*p); *p = nullptr; }
                 h->sm_nb = (int)bi.size();
                 const size_t nt_ = bcol.size();
@@ -555,7 +565,7 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bcoef, sizeof(double) * nt_));
                 HIP_TRY(h, hipMemcpy(h->sm_bptr, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice));
                 HIP_TRY(h, hipMemcpy(h->sm_bcol, bcol.data(), sizeof(int) * nt_, hipMemcpyHostToDevice));
-                HIP_TRY(h, hipMemcpy(h->sm_bcoef, bcoef.data(), sizeof(double) * nt_, hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpy(h->sm_bcoef, want_small ? bcoef.data() : bai.data(), sizeof(double) * nt_, hipMemcpyHostToDevice));
                 if (want_small) {
                     std::vector<unsigned short> si(bi.begin(), bi.end()), sk(bk.begin(), bk.end());
                     HIP_TRY(h, hipMalloc((void**)&h->sm_bi, sizeof(unsigned short) * si.size()));
@@ -568,6 +578,8 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
                     HIP_TRY(h, hipMalloc((void**)&h->ls_bk, sizeof(int) * bk.size()));
                     HIP_TRY(h, hipMemcpy(h->ls_bi, bi.data(), sizeof(int) * bi.size(), hipMemcpyHostToDevice));
                     HIP_TRY(h, hipMemcpy(h->ls_bk, bk.data(), sizeof(int) * bk.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMalloc((void**)&h->ls_bak, sizeof(double) * nt_));
+                    HIP_TRY(h, hipMemcpy(h->ls_bak, bak.data(), sizeof(double) * nt_, hipMemcpyHostToDevice));
                     h->list_form = true;
                 }
             }
@@ -726,7 +738,7 @@ static int enqueue_form(ipm_handle* h, const double* d) {
         HIP_TRY(h, hipMemsetAsync(h->B, 0, sizeof(double) * h->mp * h->mp, h->stream));
         const int work = h->sm_nb + (int)(h->mp - h->m);
         hipLaunchKernelGGL(adat_list_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, h->sm_bptr, h->ls_bi, h->ls_bk,
-                           h->sm_bcol, h->sm_bcoef, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done);
+                           h->sm_bcol, h->sm_bcoef, h->ls_bak, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done);
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }

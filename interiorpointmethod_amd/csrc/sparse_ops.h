@@ -54,24 +54,28 @@ __global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const doubl
         *reinterpret_cast<f64x2*>(out + k) = (f64x2){acc[k], acc[k + 1]};
 }
 
-// B from the PRODUCT LIST (built once on the host, ipm_set_A_csc): lower entry e = (bi[e], bk[e]) of A diag(d) A^T is
-// sum_t bcoef[t] d[bcol[t]], t in [bptr[e], bptr[e+1]) -- one thread per entry, terms in ascending column order (fixed
-// summation order, no atomics).  B was zeroed by a memset on the same stream; entries inside a 16 x 16 diagonal tile are
-// mirrored (potrf_diag reads those tiles symmetric); threads nb .. nb + (mp - m) - 1 put the unit diagonal on the
-// padding rows.  Replaces adat_sparse_kernel for sparse handles up to 4096 padded rows: that kernel gives every row of
-// B a workgroup that walks the row's nonzeros one dependent load at a time (DEGEN3: 77 us; this one: ~10 us).
+// B from the PRODUCT LIST (built once on the host, ipm_set_A_csc): entry e = (bi[e], bk[e]) of A diag(d) A^T is
+// sum_t (bai[t] d[bcol[t]]) bak[t], t in [bptr[e], bptr[e+1]) -- one thread per entry, terms in ascending column order,
+// the same products in the same order as adat_sparse_kernel forms them (coef = a_ij d_j, then coef a_kj), so B is
+// bit-identical to that kernel's.  The list holds the lower triangle plus, for every row, the entries up to the end of
+// its 16 x 16 diagonal tile (potrf_diag reads those tiles whole).  B was zeroed by a memset on the same stream; threads
+// nb .. nb + (mp - m) - 1 put the unit diagonal on the padding rows.  Replaces adat_sparse_kernel for sparse handles up
+// to 4096 padded rows: that kernel gives every row of B a workgroup that walks the row's nonzeros one dependent load
+// at a time.
 __global__ __launch_bounds__(256) void adat_list_kernel(const int* __restrict__ bptr, const int* __restrict__ bi,
                                                         const int* __restrict__ bk, const int* __restrict__ bcol,
-                                                        const double* __restrict__ bcoef, int nb, const double* __restrict__ d,
-                                                        double* B, int64_t ldb, int m, int mp, const int* done) {
+                                                        const double* __restrict__ bai, const double* __restrict__ bak, int nb,
+                                                        const double* __restrict__ d, double* B, int64_t ldb, int m, int mp,
+                                                        const int* done) {
     if (done && *done) return;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < nb) {
-        const int i = bi[e], k = bk[e];
         double acc = 0.0;
-        for (int t = bptr[e]; t < bptr[e + 1]; ++t) acc += bcoef[t] * d[bcol[t]];
-        B[(int64_t)i * ldb + k] = acc;
-        if (i != k && (i >> 4) == (k >> 4)) B[(int64_t)k * ldb + i] = acc;
+        for (int t = bptr[e]; t < bptr[e + 1]; ++t) {
+            const double coef = bai[t] * d[bcol[t]];
+            acc += coef * bak[t];
+        }
+        B[(int64_t)bi[e] * ldb + bk[e]] = acc;
     } else if (e - nb < mp - m) {
         const int r = m + (e - nb);
         B[(int64_t)r * ldb + r] = 1.0;

@@ -152,6 +152,28 @@ def test_sparse_and_dense_paths_agree(golden_dir, name):
     assert st1["objective"] == st1b["objective"] and st1["iterations"] == st1b["iterations"]   # reproducible
 
 
+@pytest.mark.parametrize("name", ["SC205", "BANDM", "DEGEN2"])
+def test_list_formation_bit_identical(golden_dir, monkeypatch, name):
+    """Sparse handles with 128 < m and <= 4096 padded rows form B from the host-built product list (adat_list_kernel, one
+    thread per entry); it performs the same products in the same order as the row-owner kernel (adat_sparse_kernel,
+    IPM_LIST_FORM=0), so B, the factor and the whole solve are bit-identical between the two."""
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    rng = np.random.default_rng(3)
+    d = 10.0 ** rng.uniform(-8, 8, A.shape[1])
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IPM_LIST_FORM", flag)
+        with ipm.IpmSolver(A, b, c) as sv:
+            B = sv.form_normal_matrix(d)
+            sv.init_state(1.0)
+            st = sv.solve(tol=1e-8, max_iter=300)
+            out[flag] = (B, sv.get_factor(), sv.get_state(), st)
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    assert out["1"][3]["iterations"] == out["0"][3]["iterations"] and out["1"][3]["status"] == 1
+    for u, v in zip(out["1"][2], out["0"][2]):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("name", ["SC50A", "BANDM", "SCSD6"])
 def test_reordered_rows_same_seam(golden_dir, name):
     """reorder="rcm" permutes the rows of A on the device (smaller tile envelope of A A^T); the seam must not

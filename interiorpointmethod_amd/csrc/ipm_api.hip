@@ -735,7 +735,9 @@ static bool overlap_residuals(const ipm_handle* h) {
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
 static int enqueue_form(ipm_handle* h, const double* d) {
     if (h->sparse && h->list_form) {
-        HIP_TRY(h, hipMemsetAsync(h->B, 0, sizeof(double) * h->mp * h->mp, h->stream));
+        const int64_t nB = h->mp * h->mp;                       // even (mp is a multiple of 128)
+        hipLaunchKernelGGL(zero_unless_done_kernel, dim3((unsigned)std::min<int64_t>((nB / 2 + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                           h->B, nB, &h->sc->done);
         const int work = h->sm_nb + (int)(h->mp - h->m);
         hipLaunchKernelGGL(adat_list_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, h->sm_bptr, h->ls_bi, h->ls_bk,
                            h->sm_bcol, h->sm_bcoef, h->ls_bak, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done);

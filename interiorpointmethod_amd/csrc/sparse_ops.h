@@ -54,6 +54,14 @@ __global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const doubl
         *reinterpret_cast<f64x2*>(out + k) = (f64x2){acc[k], acc[k + 1]};
 }
 
+// zero an n-double buffer unless the solve is done (a plain memset would wipe the factor of a converged solve when
+// iterations enqueued past convergence run as no-ops)
+__global__ __launch_bounds__(256) void zero_unless_done_kernel(double* p, int64_t n, const int* done) {
+    if (done && *done) return;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2, st = (int64_t)gridDim.x * 512;
+    for (int64_t k = i; k < n; k += st) *reinterpret_cast<f64x2*>(p + k) = (f64x2){0.0, 0.0};
+}
+
 // B from the PRODUCT LIST (built once on the host, ipm_set_A_csc): entry e = (bi[e], bk[e]) of A diag(d) A^T is
 // sum_t (bai[t] d[bcol[t]]) bak[t], t in [bptr[e], bptr[e+1]) -- one thread per entry, terms in ascending column order,
 // the same products in the same order as adat_sparse_kernel forms them (coef = a_ij d_j, then coef a_kj), so B is

@@ -72,7 +72,7 @@ struct ipm_handle {
     // fused single-workgroup path for small sparse LPs (small_lp.h): product list of B's lower entries, own allocation
     bool small = false;
     int fused_small = 1;                  // IPM_FUSED_SMALL=0: always the multi-kernel path
-    bool list_form = false;               // sparse handle, <= 4096 padded rows: B from the product list (adat_list_kernel)
+    bool list_form = false;               // sparse handle, 128 < m, <= 1536 padded rows: B from the product list (adat_list_kernel)
     int list_form_opt = 1;                // IPM_LIST_FORM=0: one workgroup per row of B (adat_sparse_kernel)
     int *ls_bi = nullptr, *ls_bk = nullptr;
     double* ls_bak = nullptr;             // list path: sm_bcoef holds a_ij, ls_bak a_kj (the products are formed on the device)
@@ -509,12 +509,14 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
             // Product list: lower entry (i, k) of B = A diag(d) A^T is sum_t coef[t] d[col[t]] over the columns that rows
             // i and k share (coef = a_ij a_kj) -- a sparse matrix-vector product with d.  Entries ordered by (i, k), terms
             // by column: a fixed summation order.  Used by the fused small-LP kernel (m <= 128) and, for sparse handles up
-            // to 4096 padded rows, by adat_list_kernel (one thread per entry instead of one workgroup per row of B walking
+            // to 1536 padded rows, by adat_list_kernel (one thread per entry instead of one workgroup per row of B walking
             // its nonzeros one dependent load at a time).
             size_t terms = 0;
             for (int64_t j = 0; j < h->n; ++j) { const size_t c = (size_t)(cp[j + 1] - cp[j]); terms += c * (c + 1) / 2; }
             const bool want_small = h->fused_small && h->m <= SMALL_MAX_M && terms <= ((size_t)1 << 22);
-            const bool want_list = h->list_form_opt && h->m > SMALL_MAX_M && h->mp <= 4096 && terms <= ((size_t)1 << 24);
+            // (measured, ms per iteration list / row-owner: SHELL (8 blocks) 0.778 / 0.810, DEGEN3 (12) 1.13 / 1.12, PILOT87 (30)
+            //  2.44 / 2.38: the zero fill of B eats the gain from 16 blocks on)
+            const bool want_list = h->list_form_opt && h->m > SMALL_MAX_M && h->mp <= 1536 && terms <= ((size_t)1 << 24);
             if (want_small || want_list) {
                 const int M = (int)h->m;
                 std::vector<int> bptr(1, 0), bi, bk, mark((size_t)M, -1), cntk((size_t)M, 0), startk((size_t)M, 0), touched;

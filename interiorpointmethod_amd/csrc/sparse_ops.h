@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void zero_unless_done_kernel(double* p, int64_
 // bit-identical to that kernel's.  The list holds the lower triangle plus, for every row, the entries up to the end of
 // its 16 x 16 diagonal tile (potrf_diag reads those tiles whole).  B was zeroed by a memset on the same stream; threads
 // nb .. nb + (mp - m) - 1 put the unit diagonal on the padding rows.  Replaces adat_sparse_kernel for sparse handles up
-// to 4096 padded rows: that kernel gives every row of B a workgroup that walks the row's nonzeros one dependent load
-// at a time.
+// to 1536 padded rows (that kernel gives every row of B a workgroup that walks the row's nonzeros one dependent load
+// at a time); beyond that the zero fill of the dense B costs what the list saves.
 __global__ __launch_bounds__(256) void adat_list_kernel(const int* __restrict__ bptr, const int* __restrict__ bi,
                                                         const int* __restrict__ bk, const int* __restrict__ bcol,
                                                         const double* __restrict__ bai, const double* __restrict__ bak, int nb,

@@ -154,7 +154,7 @@ def test_sparse_and_dense_paths_agree(golden_dir, name):
 
 @pytest.mark.parametrize("name", ["SC205", "BANDM", "DEGEN2"])
 def test_list_formation_bit_identical(golden_dir, monkeypatch, name):
-    """Sparse handles with 128 < m and <= 4096 padded rows form B from the host-built product list (adat_list_kernel, one
+    """Sparse handles with 128 < m and <= 1536 padded rows form B from the host-built product list (adat_list_kernel, one
     thread per entry); it performs the same products in the same order as the row-owner kernel (adat_sparse_kernel,
     IPM_LIST_FORM=0), so B, the factor and the whole solve are bit-identical between the two."""
     A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))

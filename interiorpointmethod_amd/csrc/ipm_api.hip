@@ -53,7 +53,8 @@ struct ipm_handle {
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
-    int grouped_trsv = 1;                 // 1024-row group inverses + GEMV solves when nblk % 8 == 0, nblk >= 16
+    int grouped_trsv = 1;                 // group inverses + GEMV solves (trsv_grouped.h); IPM_GROUPED_TRSV=0 disables
+    int gsz = 0;                          // 128-blocks per group: 8 from 16 blocks on, else the largest of 8/4/2 dividing nblk
     double *gXT = nullptr, *gX = nullptr, *gS = nullptr, *gPart = nullptr;   // own allocation
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
@@ -339,11 +340,17 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
     if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
-    if (h->grouped_trsv && h->nblk % GS == 0 && h->nblk >= 2 * GS) {
-        const size_t nG = (size_t)h->nblk / GS;
+    h->gsz = 0;
+    if (h->grouped_trsv) {
+        if (h->nblk >= 2 * GS_MAX) { if (h->nblk % GS_MAX == 0) h->gsz = GS_MAX; }
+        else for (int p2 = GS_MAX; p2 >= 2; p2 /= 2) if (h->nblk % p2 == 0) { h->gsz = p2; break; }
+        if (const char* e = getenv("IPM_GROUP_BLOCKS")) { const int v = atoi(e); if (v >= 2 && v <= GS_MAX && (v & (v - 1)) == 0 && h->nblk % v == 0) h->gsz = v; }
+    }
+    if (h->gsz > 0) {
+        const size_t nG = (size_t)h->nblk / h->gsz, GR = (size_t)h->gsz * 128;
         CREATE_TRY(hipMalloc((void**)&h->gXT, sizeof(double) * nG * GR * GR));
         CREATE_TRY(hipMalloc((void**)&h->gX, sizeof(double) * nG * GR * GR));
-        CREATE_TRY(hipMalloc((void**)&h->gS, sizeof(double) * nG * 512 * 512));
+        CREATE_TRY(hipMalloc((void**)&h->gS, sizeof(double) * nG * (GR / 2) * (GR / 2)));
         CREATE_TRY(hipMalloc((void**)&h->gPart, sizeof(double) * 16 * (size_t)h->mp));
         CREATE_TRY(hipMemset(h->gXT, 0, sizeof(double) * nG * GR * GR));     // blocks below the block diagonal stay zero
         CREATE_TRY(hipMemset(h->gX, 0, sizeof(double) * nG * GR * GR));      // blocks above the block diagonal stay zero
@@ -849,7 +856,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             // residual stream, only the last group's is left for after the factorization
             HIP_TRY(h, hipEventRecord(h->ev_grp, sm));
             HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
-            int rc_ = enqueue_group_inverses(h, 0, (k + 1) / GS, h->stream3);
+            int rc_ = enqueue_group_inverses(h, 0, (k + 1) / h->gsz, h->stream3);
             if (rc_) return rc_;
         }
         if (k == mid_step) { int rc_ = enqueue_residual_stream(h); if (rc_) return rc_; }
@@ -967,17 +974,19 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
 // groups).  After enqueue_factor, on the main stream.
 static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStream_t st = nullptr) {
     if (!h->grouped_trsv) return IPM_OK;
+    const int GS = h->gsz;
+    const int64_t GR = (int64_t)GS * 128;
     if (g1 < 0) g1 = h->nblk / GS;
     if (!st) st = h->stream;
     const int nG = g1 - g0;                               // groups [g0, g1)
     if (nG <= 0) return IPM_OK;
     const int* done = &h->sc->done;
-    hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, nG * GS), dim3(32, 8), 0, st, h->invD, h->gXT, h->gX, g0 * GS, done);
-    const int64_t gXs = (int64_t)GR * GR, gL = (int64_t)GR * (h->mp + 1), gSs = (int64_t)512 * 512;   // group strides in X/XT, L, S
+    hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, nG * GS), dim3(32, 8), 0, st, h->invD, h->gXT, h->gX, g0 * GS, GS, done);
+    const int64_t gXs = GR * GR, gL = GR * (h->mp + 1), gSs = (GR / 2) * (GR / 2);   // group strides in X/XT, L, S
     double* gXT = h->gXT + g0 * gXs; double* gX = h->gX + g0 * gXs; double* gS = h->gS + g0 * gSs;
     const double* Lg = h->B + g0 * gL;
     for (int hs = 128; hs < GR; hs *= 2) {
-        const int np = GR / (2 * hs);                     // pairs per group
+        const int np = (int)(GR / (2 * hs));              // pairs per group
         const bool small = h->ginv_variant == 1 || (h->ginv_variant == 2 && hs >= 256);   // 32 x 32 tiles: 4x the workgroups
         GemmNT t = gemm_defaults();
         t.tile_order = nullptr; t.w = nullptr; t.done = done; t.lower = 0; t.unit_diag_from = -1;
@@ -1013,6 +1022,8 @@ static void launch_dense_gemv_n(ipm_handle* h, const double* A, int64_t lda, int
 
 // out = B^{-1} r with the 1024-row group inverses: 4 group steps per sweep at m = 4096
 static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out) {
+    const int GS = h->gsz;
+    const int GR = GS * 128;
     const int nG = h->nblk / GS;
     const int* done = &h->sc->done;
     double* z = h->t2;
@@ -1130,8 +1141,8 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         // start late in the chain-bound tail: the three passes need ~0.2 ms, six steps of the chain.  Measured at 32 blocks
         // (it/s for a start at step 0 / 4 / 12 / 20 / 26 / 30): 199.5 / 199.6 / 200.6 / 201.0 / 203.1 / 200.5
         const int rstep = h->residual_step >= 0 ? std::min(h->residual_step, h->nblk - 1) : h->nblk * 13 / 16;
-        const int nG = h->grouped_trsv ? h->nblk / GS : 0;
-        const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * GS - 1 < rstep) ? (nG - 1) * GS - 1 : -1;
+        const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
+        const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
         if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
         if ((rc = enqueue_group_inverses(h, gstep >= 0 ? nG - 1 : 0, nG, nullptr))) return rc;
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));

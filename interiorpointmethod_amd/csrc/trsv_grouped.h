@@ -20,14 +20,17 @@
 
 namespace ipm {
 
-constexpr int GS = 8;                 // 128-blocks per group
-constexpr int GR = GS * 128;          // rows per group
+constexpr int GS_MAX = 8;             // 128-blocks per group: 8 from 16 blocks on (1024-row groups); smaller handles use the
+                                      // largest power of two that divides their block count (8, 4 or 2), so that an LP of 8
+                                      // blocks solves with ONE explicit inverse and two GEMVs per substitution instead of
+                                      // sixteen block-step launches
 
-// X_g[a*128 + r][a*128 + c] = inv(L_bb)[r][c] and XT_g = its transpose, for every 128-block b = 8g + a.
+// X_g[a*128 + r][a*128 + c] = inv(L_bb)[r][c] and XT_g = its transpose, for every 128-block b = GS g + a.
 // grid (4, 4, nblocks), block (32, 8).
-__global__ void group_diag_transpose_kernel(const double* __restrict__ invD, double* XT, double* X, int b0, const int* done) {
+__global__ void group_diag_transpose_kernel(const double* __restrict__ invD, double* XT, double* X, int b0, int GS, const int* done) {
     if (done && *done) return;
     __shared__ double tile[32][33];
+    const int64_t GR = (int64_t)GS * 128;
     const int b = b0 + blockIdx.z, g = b / GS, a = b % GS;
     const double* src = invD + (int64_t)b * 128 * 128;
     double* dst = XT + (int64_t)g * GR * GR + (int64_t)(a * 128) * GR + a * 128;

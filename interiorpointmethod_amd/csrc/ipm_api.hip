@@ -352,15 +352,17 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
         CREATE_TRY(hipMalloc((void**)&h->gX, sizeof(double) * nG * GR * GR));
         CREATE_TRY(hipMalloc((void**)&h->gS, sizeof(double) * nG * (GR / 2) * (GR / 2)));
         CREATE_TRY(hipMalloc((void**)&h->gPart, sizeof(double) * 16 * (size_t)h->mp));
-        CREATE_TRY(hipMemset(h->gXT, 0, sizeof(double) * nG * GR * GR));     // blocks below the block diagonal stay zero
-        CREATE_TRY(hipMemset(h->gX, 0, sizeof(double) * nG * GR * GR));      // blocks above the block diagonal stay zero
+        // (stream-ordered: a plain hipMemset runs on the NULL stream, which the handle's non-blocking streams do not
+        //  wait for -- it could land after the first group inverses were written and zero them)
+        CREATE_TRY(hipMemsetAsync(h->gXT, 0, sizeof(double) * nG * GR * GR, h->stream));     // blocks below the block diagonal stay zero
+        CREATE_TRY(hipMemsetAsync(h->gX, 0, sizeof(double) * nG * GR * GR, h->stream));      // blocks above the block diagonal stay zero
     } else {
         h->grouped_trsv = 0;
     }
     CREATE_TRY(hipMalloc((void**)&h->d_flags, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
-    CREATE_TRY(hipMemset(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
+    CREATE_TRY(hipMemsetAsync(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4), h->stream));
     CREATE_TRY(hipMalloc((void**)&h->d_bulk_done, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));   // [0,nblk) bulk, [nblk,2nblk) crit
-    CREATE_TRY(hipMemset(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4)));
+    CREATE_TRY(hipMemsetAsync(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4), h->stream));
     if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
     if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
@@ -371,7 +373,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_GROUP_HEAD")) h->group_head = atoi(e);
     if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
     if (const char* e = getenv("IPM_LIST_FORM")) h->list_form_opt = atoi(e);
-    if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->stamp_buf, 0, 8 * 64 * sizeof(long long))); }
+    if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemsetAsync(h->stamp_buf, 0, 8 * 64 * sizeof(long long), h->stream)); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));

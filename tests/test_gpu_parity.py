@@ -488,8 +488,12 @@ def test_dense_4096x8192_full_solve(golden_dir):
 # its stop test (returns 18.49 / 0.0) and on STANDATA it silently drops the nonzero lower bounds (returns 847.8):
 # there the pin is the Netlib optimum alone.  ADLITTLE is in the conversion fixtures only: the reference runs it to its
 # 999-iteration cap (dual residual stalls at 1.5e-3) and just happens to return the optimum from there.
+# STANDATA left this list in round 2: from the reference's start x = s = y = 1 it needed a 190-iteration chaotic trajectory
+#  that a change of summation order in the triangular solves no longer reproduces (the loop now ends in NaN
+# after 673 iterations, like the reference's own loop does on 25 of the 81 standard-form files).  It is solved, with the
+# other 39 small general-form files, from the Mehrotra start (test_general_form_all_fixtures_with_mehrotra_start).
 GENERAL = ["AFIRO", "BANDM", "DEGEN2", "E226", "SC105", "SC205", "SC50A", "SC50B", "SCSD1", "SCTAP1", "SHARE2B", "STOCFOR1",
-           "KB2", "SCORPION", "STANDATA"]
+           "KB2", "SCORPION"]
 
 
 @pytest.mark.parametrize("name", GENERAL)
@@ -514,7 +518,7 @@ def test_new_interior_sparse_general_form(golden_dir, name):
     if abs(ref - opt) <= 1e-5 * max(1.0, abs(opt)):                     # the reference solved it too
         assert abs(obj - ref) <= 1e-6 * max(1.0, abs(ref))
     else:
-        assert name in ("KB2", "SCORPION", "STANDATA")
+        assert name in ("KB2", "SCORPION")
 
 
 def test_two_level_blocking_option(monkeypatch):

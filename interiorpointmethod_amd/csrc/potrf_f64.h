@@ -295,49 +295,36 @@ constexpr int PD_THREADS = 512;      // 8 waves: wave 0 runs the serial pivot ch
 // (small_lp.h) calls it with nt = ceil(m / 16).
 struct NoEarlyWork { __device__ __forceinline__ void operator()() const {} };
 
-template <bool STAMP, typename Early = NoEarlyWork, typename FinishLoad = NoEarlyWork>
+template <bool STAMP, typename Early = NoEarlyWork>
 __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, double thresh, double big, long long* stamps,
-                                         Early early = Early(), FinishLoad finish_load = FinishLoad()) {
-    __shared__ int p2_done;                               // waves 1..7 that finished their substitution rows, all panels
+                                         Early early = Early()) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     int nfix = 0;
-    if (tid == 0) p2_done = 0;
-    // `finish_load` (optional): the caller has so far brought in only what the first pivot tile needs; waves 1..7 bring in
-    // the rest of the block while wave 0 factors tile 0, wave 0 follows with its own share
     if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, big, dinv_s);
-    finish_load();
     IPM_STAMP(2);
     __syncthreads();
     IPM_STAMP(3);
 
-    // Phase schedule per 16-wide panel jb (two workgroup barriers per panel):
-    //   P2a(jb): forward substitution of the 16 rows of tile row jb+1 only (waves 0..3, one pass of four rows each) --
-    //            all that the next pivot tile needs
-    //   barrier
+    // Phase schedule per 16-wide panel jb (two barriers per panel):
+    //   P2(jb): forward substitution of the panel rows below tile jb, four rows per wave pass (DPP form)
     //   P3(jb): wave 0 : update tile (jb+1,jb+1) and factor it (runs ahead on the serial pivot chain)
-    //           waves 1..7: P2b = substitution of the remaining panel rows, then a 7-wave rendezvous on an LDS counter
-    //                       (wave 0 is not part of it), then
-    //             wave 7 : invert tile jb, then shares the item list
-    //             waves 1..6: item list = rest of the trailing update of panel jb, then block row jb-1 of
-    //                         inv(L) (its diagonal tile inverse was produced in P3(jb-1))
-    //   barrier
-    // (round 1 substituted ALL rows before the first barrier: 3.9k cycles of the first panel's 10.7k sat in front of the
-    //  pivot chain; now 1.0k do.)
+    //           wave 7 : invert tile jb, then shares the item list
+    //           waves 1..6: item list = rest of the trailing update of panel jb, then block row jb-1 of
+    //                       inv(L) (its diagonal tile inverse was produced in P3(jb-1))
     for (int jb = 0; jb < nt; ++jb) {
         const int c0 = jb * 16;
         const int nrt = nt - jb - 1;                      // 16-row tiles below the pivot tile
-        double trow[16];
-        double dc = 0.0;
         if (nrt > 0) {
+            double trow[16];
 #pragma unroll
             for (int k = 0; k < 16; k += 2) {
                 f64x2 v = *reinterpret_cast<const f64x2*>(&W[(c0 + fr) * WLD + c0 + k]);
                 trow[k] = (k < fr) ? v.x : 0.0; trow[k + 1] = (k + 1 < fr) ? v.y : 0.0;      // strictly lower part of row fr
             }
-            dc = dinv_s[c0 + fr];
-            if (wave < 4) substitute_rows4(W, c0, c0 + 16 + 4 * wave, lane, trow, dc);          // P2a: rows of tile row jb+1
+            const double dc = dinv_s[c0 + fr];
+            for (int g = wave; g < 4 * nrt; g += 8) substitute_rows4(W, c0, c0 + 16 + 4 * g, lane, trow, dc);
         }
         IPM_STAMP(4 + jb * 4);
         __syncthreads();
@@ -346,14 +333,6 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
             const f64x4 nxt = update_tile_regs(W, c0, c0 + 16, c0 + 16, fr, fk);     // stays in registers
             nfix += factor_tile(W, c0 + 16, lane, thresh, big, dinv_s, &nxt);
         } else {
-            if (nrt > 0) {
-                // P2b: the other rows of the panel, then wait until all seven waves are through (the trailing update
-                // below reads rows substituted by other waves).  The counter only grows: 7 per panel.
-                for (int g = 4 + (wave - 1); g < 4 * nrt; g += 7) substitute_rows4(W, c0, c0 + 16 + 4 * g, lane, trow, dc);
-                if (lane == 0) __hip_atomic_fetch_add(&p2_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int want = 7 * (jb + 1);
-                while (__hip_atomic_load(&p2_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
-            }
             // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1.
             // Wave 7 only inverts tile jb (about as long as wave 0's factorization) while a pivot tile is
             // left; the item list is shared by waves 1..6 (all 8 waves on the last panel).
@@ -404,28 +383,24 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     long long* stamps = a.stamps;
 
     IPM_STAMP(0);
-    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a thread are issued
-    //      up front (one memory latency).  Only rows 0..15 -- the first pivot tile -- are written to LDS before the first
-    //      barrier; the other rows land while wave 0 already factors that tile (finish_load, see potrf_lds).
-    f64x2 v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        int idx = tid + u * PD_THREADS;
-        int i = idx >> 6, c2 = (idx & 63) * 2;
-        v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
-    }
-    auto write_lds = [&](int u0, int u1) {
+    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a
+    //      thread are issued before the first LDS write (one memory latency)
+    {
+        f64x2 v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            if (u < u0 || u >= u1) continue;
+            int idx = tid + u * PD_THREADS;
+            int i = idx >> 6, c2 = (idx & 63) * 2;
+            v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
             int idx = tid + u * PD_THREADS;
             int i = idx >> 6, c2 = (idx & 63) * 2;
             if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
-    };
-    const bool shifted = a.shift_rel != 0.0;              // Tikhonov shift: needs the whole diagonal in LDS first
-    write_lds(0, shifted ? 16 : 2);                       // u = 0, 1 cover rows 0..15
-    if (shifted) {
+    }
+    if (a.shift_rel != 0.0) {
         __syncthreads();
         if (tid < NB) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
     }
@@ -452,8 +427,7 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
         }
     };
     const int nfix = potrf_lds<STAMP>(W, dinv_s, NB / 16, thresh, a.big, stamps,
-                                      [&]() { write_rows(0, 16, true, 0, NB - 16); },
-                                      [&]() { if (!shifted) write_lds(2, 16); });
+                                      [&]() { write_rows(0, 16, true, 0, NB - 16); });
     write_rows(14, 16, false, NB - 16, NB);           // u = 14, 15 cover rows 112..127
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);

@@ -7,6 +7,7 @@
 // satisfied stop test are no-ops (they test Scalars::done first), so running ahead of the
 // host check never changes the result.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -45,6 +46,10 @@ struct ipm_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t stream2 = nullptr;            // bulk stream of the Cholesky look-ahead
+    hipStream_t stream_chain = nullptr;       // pivot-chain stream restricted to the 32 CUs of one XCD (IPM_CHAIN_XCD=1): the three
+                                              // chain kernels of a step then hand their 128 KB blocks over through that XCD's L2
+    hipEvent_t ev_join = nullptr;
+    int chain_xcd = 0;
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
     hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr;
     int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
@@ -377,6 +382,18 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    if (const char* e = getenv("IPM_CHAIN_XCD")) h->chain_xcd = atoi(e);
+    if (h->chain_xcd) {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        if (ncu >= 64 && ncu % 8 == 0) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);          // mask bit i <-> XCD i % 8 (tools/prio_probe.hip)
+            for (int i = 0; i < ncu; i += 8) mask[(size_t)i / 32] |= 1u << (i % 32);
+            CREATE_TRY(hipExtStreamCreateWithCUMask(&h->stream_chain, (uint32_t)mask.size(), mask.data()));
+            CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+    }
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
@@ -412,6 +429,8 @@ extern "C" int ipm_destroy(ipm_handle* h) {
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
+    if (h->stream_chain) { (void)hipStreamSynchronize(h->stream_chain); (void)hipStreamDestroy(h->stream_chain); }
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->ev_res) (void)hipEventDestroy(h->ev_res);
     if (h->ev_grp) (void)hipEventDestroy(h->ev_grp);
@@ -729,8 +748,8 @@ static int enqueue_residuals(ipm_handle* h, hipStream_t st = nullptr) {
 // predictor's right-hand side, three of the six passes over A -- runs on its own stream while the pivot chain of the
 // factorization leaves most of the chip idle.  Called from inside enqueue_factor once the chain-bound tail begins (the
 // head of the factorization is bound by its trailing updates, which these HBM passes would only slow down).
-static int enqueue_residual_stream(ipm_handle* h) {
-    HIP_TRY(h, hipEventRecord(h->ev_mid, h->stream));
+static int enqueue_residual_stream(ipm_handle* h, hipStream_t chain) {
+    HIP_TRY(h, hipEventRecord(h->ev_mid, chain));
     HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_mid, 0));
     int rc = enqueue_residuals(h, h->stream3);
     if (rc) return rc;
@@ -829,7 +848,12 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         }
         h->last_gs = (gs == 1 && head > 0) ? 2 : gs;
     }
-    hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
+    const bool own_chain = la && h->stream_chain != nullptr;
+    hipStream_t sm = own_chain ? h->stream_chain : h->stream, sb = la ? h->stream2 : h->stream;
+    if (own_chain) {
+        HIP_TRY(h, hipEventRecord(h->ev_join, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_join, 0));
+    }
     // device-polled hand-offs only while this is the one live handle on the device (see g_live)
     const bool alone = h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
     const bool fs = la && h->flag_sync != 0 && alone;
@@ -861,7 +885,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             int rc_ = enqueue_group_inverses(h, 0, (k + 1) / h->gsz, h->stream3);
             if (rc_) return rc_;
         }
-        if (k == mid_step) { int rc_ = enqueue_residual_stream(h); if (rc_) return rc_; }
+        if (k == mid_step) { int rc_ = enqueue_residual_stream(h, sm); if (rc_) return rc_; }
         int rem = (int)(h->mp - (int64_t)(k + 1) * NB);
         if (rem <= 0) break;
         if (use_env) {                                              // rows below the envelope are zero and stay zero
@@ -967,6 +991,10 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }
     if (la) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[h->nblk - 2], 0));
+    if (own_chain) {
+        HIP_TRY(h, hipEventRecord(h->ev_join, sm));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    }
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }

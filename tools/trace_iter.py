@@ -1,9 +1,11 @@
-"""Print the kernel timeline of one iteration from a rocprofv3 --kernel-trace CSV (anchored at the Nth prepare_kernel)."""
+"""Print the kernel timeline of one iteration from a rocprofv3 --kernel-trace CSV: python tools/trace_iter.py DIR [N [ANCHOR]]
+(anchored at the Nth scaling_kernel -- the first kernel of an iteration on dense handles -- or prepare_kernel)."""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'prepare_kernel' in r['Kernel_Name']]
+anchor = sys.argv[3] if len(sys.argv) > 3 else ('scaling_kernel' if any('scaling_kernel' in r['Kernel_Name'] for r in rows) else 'prepare_kernel')
+idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
 nth = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 a, b = idx[nth], idx[nth + 1]
 t0 = int(rows[a]['Start_Timestamp'])

@@ -52,7 +52,15 @@ __global__ __launch_bounds__(256) void sub_partials_kernel(double* z, const doub
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= np) return;
     double s = 0.0;
-    for (int r = 0; r < rc; ++r) s += part[(int64_t)r * np + c];
+    int r = 0;
+    for (; r + 8 <= rc; r += 8) {                          // eight loads in flight, summed in chunk order
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = part[(int64_t)(r + q) * np + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += t[q];
+    }
+    for (; r < rc; ++r) s += part[(int64_t)r * np + c];
     z[c] -= s;
 }
 

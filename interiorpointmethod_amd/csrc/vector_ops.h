@@ -139,9 +139,20 @@ struct VecArgs {
     IterRec* hist;                 // [HIST_CAP] ring of per-iteration records
 };
 
+// sum over the row chunks of the GEMV-T partials, in chunk order (fixed order: bitwise reproducible).  Eight loads are in
+// flight at a time: a plain loop waits for every load before it issues the next one (32 chunks = 32 L2 latencies, 13 us of
+// direction_kernel's 13 us at n = 8192).
 __device__ __forceinline__ double col_sum(const double* atp, int rc_chunks, int np, int j) {
     double s = 0.0;
-    for (int r = 0; r < rc_chunks; ++r) s += atp[(int64_t)r * np + j];
+    int r = 0;
+    for (; r + 8 <= rc_chunks; r += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = atp[(int64_t)(r + q) * np + j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += t[q];
+    }
+    for (; r < rc_chunks; ++r) s += atp[(int64_t)r * np + j];
     return s;
 }
 

@@ -51,7 +51,7 @@ struct ipm_handle {
     hipEvent_t ev_join = nullptr;
     int chain_xcd = 0;
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
-    hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr;
+    hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr, ev_last = nullptr;
     int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
     int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
     int residual_step = -1;                   // factorization step at which the residual stream starts (-1: 13/16 nblk; IPM_RESIDUAL_STEP)
@@ -397,6 +397,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
     if (const char* e = getenv("IPM_RESIDUAL_STEP")) h->residual_step = atoi(e);
@@ -434,6 +435,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->ev_res) (void)hipEventDestroy(h->ev_res);
     if (h->ev_grp) (void)hipEventDestroy(h->ev_grp);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1051,13 +1053,16 @@ static void launch_dense_gemv_n(ipm_handle* h, const double* A, int64_t lda, int
 }
 
 // out = B^{-1} r with the 1024-row group inverses: 4 group steps per sweep at m = 4096
-static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out) {
+// wait_last (optional): event after which the LAST group's inverse is available; the forward sweep over the earlier groups
+// does not need it and runs ahead of the wait
+static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out, hipEvent_t wait_last = nullptr) {
     const int GS = h->gsz;
     const int GR = GS * 128;
     const int nG = h->nblk / GS;
     const int* done = &h->sc->done;
     double* z = h->t2;
     for (int g = 0; g < nG; ++g) {                                        // forward: L z = r
+        if (wait_last && g == nG - 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, wait_last, 0));
         launch_dense_gemv_n(h, h->gX + (int64_t)g * GR * GR, GR, GR, GR, r + (int64_t)g * GR, 1.0, 0.0, nullptr, z + (int64_t)g * GR);
         int below = (int)(h->mp - (int64_t)(g + 1) * GR);
         if (h->use_env) below = std::min(below, (int)((int64_t)(h->env_last[(g + 1) * GS - 1] + 1) * NB - (int64_t)(g + 1) * GR));
@@ -1084,8 +1089,9 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out) {
 }
 
 // out = B^{-1} r  (r is consumed; uses t2 as the intermediate)
-static int enqueue_potrs(ipm_handle* h, double* r, double* out) {
-    if (h->grouped_trsv) return enqueue_potrs_grouped(h, r, out);
+static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_last = nullptr) {
+    if (h->grouped_trsv) return enqueue_potrs_grouped(h, r, out, wait_last);
+    if (wait_last) HIP_TRY(h, hipStreamWaitEvent(h->stream, wait_last, 0));
     if (h->persistent_trsv && h->nblk >= 2 && h->nblk <= 240) {
         // flags: [0,nblk) forward, [nblk,2nblk) backward, then the timeout word; zeroed per call
         HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk), h->stream));
@@ -1118,11 +1124,11 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out) {
     return IPM_OK;
 }
 
-static int enqueue_predictor(ipm_handle* h, hipEvent_t* ev, bool have_rhs = false) {
+static int enqueue_predictor(ipm_handle* h, hipEvent_t* ev, bool have_rhs = false, hipEvent_t wait_last = nullptr) {
     VecArgs a = vec_args(h);
     if (!have_rhs) launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);   // rhs = -r_b - A (d*t)
     if (ev) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
-    int rc = enqueue_potrs(h, h->t1, h->dya);
+    int rc = enqueue_potrs(h, h->t1, h->dya, wait_last);
     if (rc) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     launch_gemv_t(h, h->dya);
@@ -1174,9 +1180,20 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
         const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
         if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
-        if ((rc = enqueue_group_inverses(h, gstep >= 0 ? nG - 1 : 0, nG, nullptr))) return rc;
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));
-        if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;
+        if (gstep >= 0) {
+            // the last group's inverse (nine dependent launches, ~80 us) goes to the residual stream as well: the forward
+            // sweep of the predictor over the earlier groups runs beside it and only its last step waits
+            HIP_TRY(h, hipEventRecord(h->ev_grp, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
+            if ((rc = enqueue_group_inverses(h, nG - 1, nG, h->stream3))) return rc;
+            HIP_TRY(h, hipEventRecord(h->ev_last, h->stream3));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));
+            if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true, h->ev_last))) return rc;
+        } else {
+            if ((rc = enqueue_group_inverses(h, 0, nG, nullptr))) return rc;
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));
+            if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;
+        }
         if ((rc = enqueue_corrector(h, nullptr))) return rc;
         if ((rc = enqueue_update(h))) return rc;
         return IPM_OK;

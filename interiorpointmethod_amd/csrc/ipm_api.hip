@@ -1324,7 +1324,7 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
     return IPM_OK;
 }
 
-// diagnostic: copy the s_memtime stamps of the first diagonal-block factorization (4 waves x 64 slots)
+// diagnostic: copy the s_memtime stamps of the first diagonal-block factorization (8 waves x 64 slots)
 extern "C" int ipm_debug_get_stamps(ipm_handle* h, long long* out) {
     if (!h || !out || !h->stamp_buf) return fail(h, IPM_ERR_STATE, "stamps not enabled (IPM_POTRF_STAMPS=1)");
     HIP_TRY(h, hipMemcpy(out, h->stamp_buf, 8 * 64 * sizeof(long long), hipMemcpyDeviceToHost));

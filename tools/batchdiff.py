@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Diagnostic: the 73-LP Netlib suite through batch.run_batch with two LPs in flight, one at a time, and two in flight again;
+prints every LP whose (status, iterations, objective) record differs between the runs (expected: none -- the sync mechanism
+of concurrent handles must not change arithmetic)."""
 import glob, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <utility>
 
 using namespace ipm;
@@ -381,7 +382,12 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemsetAsync(h->stamp_buf, 0, 8 * 64 * sizeof(long long), h->stream)); }
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
+    // The residual stream exists only where it is used (dense handles from 16 blocks on): the HIP runtime maps streams onto a
+    // handful of hardware queues in creation order, and an idle third stream per handle pushes the streams of the NEXT handle
+    // onto queues that this handle's chain already occupies (two concurrent solves then serialise: tools/concurrency_probe.py)
+    if (h->overlap_res && !h->sparse && h->lookahead != 0 && h->nblk >= 16)
+        CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
     if (const char* e = getenv("IPM_CHAIN_XCD")) h->chain_xcd = atoi(e);
     if (h->chain_xcd) {
         hipDeviceProp_t prop;
@@ -399,7 +405,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
-    if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
     if (const char* e = getenv("IPM_RESIDUAL_STEP")) h->residual_step = atoi(e);
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
     for (int k = 0; k < h->nblk; ++k) {
@@ -761,7 +766,7 @@ static int enqueue_residual_stream(ipm_handle* h, hipStream_t chain) {
     return IPM_OK;
 }
 static bool overlap_residuals(const ipm_handle* h) {
-    return h->overlap_res != 0 && !h->sparse && h->lookahead != 0 && h->nblk >= 16 && h->profiling < 2;
+    return h->stream3 != nullptr && h->profiling < 2;          // (created for dense handles from 16 blocks on, ipm_create)
 }
 
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
@@ -1456,14 +1461,21 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     }
     bool first = true;
     int recovered = 0;
+    static const bool host_timing = getenv("IPM_HOST_TIMING") != nullptr;        // diagnostic: where the host thread spends a solve
+    double t_enq = 0.0, t_wait = 0.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct Report { const bool on; const double &a, &b; const ipm_handle* h; ~Report() { if (on) fprintf(stderr, "[ipm host] m=%lld: enqueue %.1f ms, wait %.1f ms\n", (long long)h->m, a * 1e3, b * 1e3); } } report{host_timing, t_enq, t_wait, h};
     for (;;) {
         // roll-back point: the first chunk (auto-regularize restart) and every chunk that can hit a poll time-out
         const bool snap = first || may_poll(h);
+        const double t0 = host_timing ? now() : 0.0;
         if (snap && (rc = enqueue_snapshot(h, 0))) return rc;
         for (int i = 0; i < chunk; ++i)
             if ((rc = enqueue_iteration(h, nullptr))) return rc;
+        const double t1 = host_timing ? now() : 0.0;
         bool tmo = false;
         if ((rc = read_scalars(h, &tmo))) return rc;
+        if (host_timing) { t_enq += t1 - t0; t_wait += now() - t1; }
         if (tmo) {
             if (!snap || ++recovered > 2) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
             poll_fallback(h);

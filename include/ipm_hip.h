@@ -64,7 +64,13 @@ enum {
      * more than 5 % of its pivots (A has that many dependent rows: the QAP family of Netlib, 9-16 %; no other Netlib
      * file exceeds 2.7 %) and restarts the solve from its start state; the guard alone stalls there.
      * Reported in ipm_stats.auto_regularized.  This flag keeps the shift off. */
-    IPM_FLAG_NO_AUTO_REGULARIZE = 2
+    IPM_FLAG_NO_AUTO_REGULARIZE = 2,
+    /* One stream per handle: the blocked Cholesky runs without its look-ahead on a second stream (10-25 % slower for
+     * a solve that has the GPU to itself).  For SEVERAL handles driven concurrently on one GPU this is the faster
+     * setting by far: the HIP runtime maps streams onto four hardware queues, a mid-size LP keeps only a few CUs busy,
+     * and four single-stream solves overlap almost perfectly (4 x DEGEN3: 1.15x the time of one) where two-stream
+     * handles share queues and serialise (2.4x).  The batched mode of the Python host sets it. */
+    IPM_FLAG_SINGLE_STREAM = 4
 };
 
 typedef struct ipm_handle ipm_handle;

@@ -26,6 +26,7 @@ IPM_OK = 0
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NAN = 0, 1, 2, 3
 FLAG_NO_DEVICE_POLLING = 1      # include/ipm_hip.h: IPM_FLAG_NO_DEVICE_POLLING
 FLAG_NO_AUTO_REGULARIZE = 2     # include/ipm_hip.h: IPM_FLAG_NO_AUTO_REGULARIZE
+FLAG_SINGLE_STREAM = 4          # include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM
 ABI_VERSION = 2
 HISTORY_CAPACITY = 1024         # IPM_HISTORY_CAPACITY
 ERR_INVALID_INPUT = -6

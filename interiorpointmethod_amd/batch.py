@@ -100,12 +100,13 @@ SMALL_ROWS = 1 << 30    # LPs up to this many rows share the GPU with each other
 def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
     """Solve problems[i] for i in ids on this rank's GPU -> (len(ids), NF) float64 records.
 
-    workers > 1: the LPs with at most SMALL_ROWS rows are solved `workers` at a time from host threads, each
-    handle on its own stream.  A small LP is a chain of ~60 launch-bound kernels per iteration that uses a few
-    CUs, so several of them interleave on one GPU almost for free; results do not depend on the interleaving (every
-    handle is independent and deterministic).  Such handles are created with IPM_FLAG_NO_DEVICE_POLLING: HIP maps
-    streams onto a few hardware queues, and a kernel that polls for a counter can end up queued in front of its own
-    producer (measured: 3.3 s poll timeouts).  Larger LPs run one at a time first, with the polling hand-offs."""
+    workers > 1: the LPs are solved `workers` at a time from host threads, each handle on ONE stream of its own
+    (IPM_FLAG_SINGLE_STREAM | IPM_FLAG_NO_DEVICE_POLLING): a mid-size LP is a latency chain that keeps a few CUs busy,
+    so several of them overlap on one GPU -- provided their streams do not share hardware queues.  The HIP runtime has
+    four; with the two-stream look-ahead of a lone solve two LPs already collide (2 x DEGEN3: 1.3x the time of one, 3 x:
+    2.4x), with one stream per handle four overlap almost perfectly (4 x: 1.15x; tools/concurrency_probe.py) although
+    each solve alone is 10-25 % slower without the look-ahead.  Results do not depend on the interleaving (every handle
+    is independent and deterministic, and both schedules perform the same arithmetic)."""
     rec = np.zeros((len(ids), NF), dtype=np.float64)
 
     def one(row_i):

@@ -344,6 +344,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
+    if (h->opt.flags & IPM_FLAG_SINGLE_STREAM) h->lookahead = 0;
     if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
     h->gsz = 0;
@@ -380,7 +381,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
     if (const char* e = getenv("IPM_LIST_FORM")) h->list_form_opt = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(hipMalloc((void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemsetAsync(h->stamp_buf, 0, 8 * 64 * sizeof(long long), h->stream)); }
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    if (h->lookahead != 0 && h->nblk > 2)                  // (a single-stream handle creates no second stream: see stream3 below)
+        CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
     // The residual stream exists only where it is used (dense handles from 16 blocks on): the HIP runtime maps streams onto a
@@ -825,7 +827,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
-    const bool la = h->lookahead != 0 && h->nblk > 2;
+    const bool la = h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr;
     // group size of the two-level schedule.  Measured (factor, ms): 16384 x 32768: 39.7 / 34.9 / 33.4 / 32.9 / 32.5 for groups
     // of 1 / 2 / 3 / 4 / 6; 8192 x 16384: 7.87 / 7.46 / 7.34 / 7.34 for 1 / 2 / 3 / 4; but 4096 x 8192: 2.21 -> 2.36 with groups
     // of 2 (half of its steps are bound by the pivot chain, which grouping lengthens): on from 48 blocks.
@@ -1227,7 +1229,7 @@ static int read_scalars(ipm_handle* h, bool* timed_out = nullptr) {
     HIP_TRY(h, hipMemcpyAsync(&tmo, word, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (tmo) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream2));               // the bulk stream may still be draining
+        if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));               // the bulk stream may still be draining
         HIP_TRY(h, hipMemsetAsync(word, 0, sizeof(unsigned), h->stream));
         if (!timed_out) return fail(h, IPM_ERR_HIP, "a device-side hand-off poll timed out (persistent solve)");
     }
@@ -1268,7 +1270,7 @@ static int enqueue_snapshot(ipm_handle* h, int restore) {
     return IPM_OK;
 }
 // can the next factorization time out at all?  (mirrors the `fs` rule of enqueue_factor)
-static bool may_poll(const ipm_handle* h) { return h->lookahead != 0 && h->nblk > 2 && h->flag_sync != 0; }
+static bool may_poll(const ipm_handle* h) { return h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
 
 static void fill_stats(ipm_handle* h, ipm_stats* st, double ms) {
     if (!st) return;

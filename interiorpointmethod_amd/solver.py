@@ -138,9 +138,10 @@ class IpmSolver:
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
         opts.check_every = int(check_every)
         opts.regularize = float(regularize)
-        # concurrent=True forces stream events from the start; without it the library still protects itself (it counts
-        # the live handles per device and falls back to events, include/ipm_hip.h)
-        opts.flags = (_lib.FLAG_NO_DEVICE_POLLING if concurrent else 0) | \
+        # concurrent=True: this handle shares the GPU with others (batched mode) -- one stream per handle, no look-ahead, no
+        # device polling (include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM).  Without it the library still protects itself (it
+        # counts the live handles per device and falls back to stream events).
+        opts.flags = ((_lib.FLAG_NO_DEVICE_POLLING | _lib.FLAG_SINGLE_STREAM) if concurrent else 0) | \
                      (0 if auto_regularize else _lib.FLAG_NO_AUTO_REGULARIZE)
         nbytes = C.c_size_t(0)
         self.sparse = _sp is not None and _sp.issparse(A)

@@ -325,7 +325,7 @@ def main():
                     help="all 73 valid standard-form files, the 26 on which the reference converges, or the 72 general-form "
                          "files (benchmarks_full) through the general-form front end")
     ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
-    ap.add_argument("--workers", type=int, default=4, help="netlib: LPs in flight per GPU, each on one stream (1 = strictly one at a time, with the look-ahead)")
+    ap.add_argument("--workers", type=int, default=8, help="netlib: LPs in flight per GPU, each on one stream (1 = strictly one at a time, with the look-ahead)")
     ap.add_argument("--schedule", default="dynamic", choices=["dynamic", "static"],
                     help="netlib, N > 1: pull LPs from a shared counter (rendezvous store) or static LPT partition")
     ap.add_argument("--start-point", dest="start", default="reference", choices=["reference", "mehrotra"],
@@ -458,15 +458,15 @@ def main():
             from interiorpointmethod_amd import batch
             names, probs, flops = load_netlib("parity")
             batch.solve_one(probs[names.index("AFIRO")], device=dev)         # warm-up
-            rec, el = run_netlib(names, probs, flops, dev, workers=4)
+            rec, el = run_netlib(names, probs, flops, dev, workers=8)
             summ = batch.summarize(rec)
-            out["netlib"] = {"metric": "Netlib LPs/sec (26-LP parity set of benchmarks/, tol=1e-8, cap 300, 4 LPs in flight)",
+            out["netlib"] = {"metric": "Netlib LPs/sec (26-LP parity set of benchmarks/, tol=1e-8, cap 300, 8 LPs in flight)",
                              "value": summ["converged"] / el, "unit": "LPs/s", "n_gpus": 1, "wall_seconds": el,
                              "summary": summ, "roofline": netlib_roofline(names, probs, flops, rec, el, 1),
                              "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)} for r in rec}}
             if not args.no_cpu_baseline:
                 cb = netlib_cpu_baseline(names, probs)
-                # the same LPs on the GPU (their share of the run above; four LPs were in flight, so this is an upper bound)
+                # the same LPs on the GPU (their share of the run above; eight LPs were in flight, so this is an upper bound)
                 cb["gpu_seconds_same_sample"] = float(sum(r[7] for r in rec if names[int(r[0])] in cb["sample_names"]))
                 out["netlib"]["cpu_baseline"] = cb
         print(json.dumps(out))

@@ -453,7 +453,7 @@ def main():
             if (m, n) == (M_DEFAULT, N_DEFAULT):
                 out["cpu_baseline_reference_algorithm"] = cpu_baseline_reference_algorithm(A, b, c)
         if world == 1 and not args.no_netlib and (m, n) == (M_DEFAULT, N_DEFAULT):
-            # second half of the headline metric on the same GPU: the 26-LP parity set, two LPs in flight
+            # second half of the headline metric on the same GPU: the 26-LP parity set, eight LPs in flight (one stream each)
             sv.close()
             from interiorpointmethod_amd import batch
             names, probs, flops = load_netlib("parity")

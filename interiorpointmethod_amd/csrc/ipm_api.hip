@@ -54,7 +54,11 @@ struct ipm_handle {
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
     hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr, ev_last = nullptr;
     int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
-    int use_graph = 1;                        // single-stream handles replay captured chunks of iterations (IPM_GRAPH=0 disables)
+    int use_graph = 0;                        // IPM_GRAPH=1: single-stream handles replay captured chunks of iterations.  Measured:
+                                              // host enqueue time of a solve 94 -> 11 ms, but the 73-LP suite with 8-12 LPs in flight is
+                                              // no faster (3.8-4.4 s either way: GPU-side queueing, not launches, bounds it), and while a
+                                              // capture is open ANY legacy-stream call of ANOTHER host thread fails ("would make the legacy
+                                              // stream depend on a capturing blocking stream") -- not something a drop-in library may cause
     int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
     int residual_step = -1;                   // factorization step at which the residual stream starts (-1: 13/16 nblk; IPM_RESIDUAL_STEP)
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
@@ -604,25 +608,28 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bptr, sizeof(int) * bptr.size()));
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bcol, sizeof(int) * nt_));
                 HIP_TRY(h, hipMalloc((void**)&h->sm_bcoef, sizeof(double) * nt_));
-                HIP_TRY(h, hipMemcpy(h->sm_bptr, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice));
-                HIP_TRY(h, hipMemcpy(h->sm_bcol, bcol.data(), sizeof(int) * nt_, hipMemcpyHostToDevice));
-                HIP_TRY(h, hipMemcpy(h->sm_bcoef, want_small ? bcoef.data() : bai.data(), sizeof(double) * nt_, hipMemcpyHostToDevice));
+                HIP_TRY(h, hipMemcpyAsync(h->sm_bptr, bptr.data(), sizeof(int) * bptr.size(), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(h->sm_bcol, bcol.data(), sizeof(int) * nt_, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(h->sm_bcoef, want_small ? bcoef.data() : bai.data(), sizeof(double) * nt_, hipMemcpyHostToDevice, h->stream));
                 if (want_small) {
                     std::vector<unsigned short> si(bi.begin(), bi.end()), sk(bk.begin(), bk.end());
                     HIP_TRY(h, hipMalloc((void**)&h->sm_bi, sizeof(unsigned short) * si.size()));
                     HIP_TRY(h, hipMalloc((void**)&h->sm_bk, sizeof(unsigned short) * sk.size()));
-                    HIP_TRY(h, hipMemcpy(h->sm_bi, si.data(), sizeof(unsigned short) * si.size(), hipMemcpyHostToDevice));
-                    HIP_TRY(h, hipMemcpy(h->sm_bk, sk.data(), sizeof(unsigned short) * sk.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpyAsync(h->sm_bi, si.data(), sizeof(unsigned short) * si.size(), hipMemcpyHostToDevice, h->stream));
+                    HIP_TRY(h, hipMemcpyAsync(h->sm_bk, sk.data(), sizeof(unsigned short) * sk.size(), hipMemcpyHostToDevice, h->stream));
                     h->small = true;
                 } else {
                     HIP_TRY(h, hipMalloc((void**)&h->ls_bi, sizeof(int) * bi.size()));
                     HIP_TRY(h, hipMalloc((void**)&h->ls_bk, sizeof(int) * bk.size()));
-                    HIP_TRY(h, hipMemcpy(h->ls_bi, bi.data(), sizeof(int) * bi.size(), hipMemcpyHostToDevice));
-                    HIP_TRY(h, hipMemcpy(h->ls_bk, bk.data(), sizeof(int) * bk.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpyAsync(h->ls_bi, bi.data(), sizeof(int) * bi.size(), hipMemcpyHostToDevice, h->stream));
+                    HIP_TRY(h, hipMemcpyAsync(h->ls_bk, bk.data(), sizeof(int) * bk.size(), hipMemcpyHostToDevice, h->stream));
                     HIP_TRY(h, hipMalloc((void**)&h->ls_bak, sizeof(double) * nt_));
-                    HIP_TRY(h, hipMemcpy(h->ls_bak, bak.data(), sizeof(double) * nt_, hipMemcpyHostToDevice));
+                    HIP_TRY(h, hipMemcpyAsync(h->ls_bak, bak.data(), sizeof(double) * nt_, hipMemcpyHostToDevice, h->stream));
                     h->list_form = true;
                 }
+                // (stream-ordered copies + one sync: the library issues NO legacy-stream operation -- another host thread may
+                //  be capturing a graph on a blocking stream, which a NULL-stream copy would illegally depend on)
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
             }
         }
         return IPM_OK;
@@ -1336,7 +1343,8 @@ extern "C" int ipm_newton_direction(ipm_handle* h, int corrector, double* dx, do
 // diagnostic: copy the s_memtime stamps of the first diagonal-block factorization (8 waves x 64 slots)
 extern "C" int ipm_debug_get_stamps(ipm_handle* h, long long* out) {
     if (!h || !out || !h->stamp_buf) return fail(h, IPM_ERR_STATE, "stamps not enabled (IPM_POTRF_STAMPS=1)");
-    HIP_TRY(h, hipMemcpy(out, h->stamp_buf, 8 * 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpyAsync(out, h->stamp_buf, 8 * 64 * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return IPM_OK;
 }
 
@@ -1469,9 +1477,8 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     double t_enq = 0.0, t_wait = 0.0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     struct Report { const bool on; const double &a, &b; const ipm_handle* h; ~Report() { if (on) fprintf(stderr, "[ipm host] m=%lld: enqueue %.1f ms, wait %.1f ms\n", (long long)h->m, a * 1e3, b * 1e3); } } report{host_timing, t_enq, t_wait, h};
-    // Single-stream handles (batched mode: several solves share the GPU and the host is launch bound, 30-40 % of a lone
-    // solve is spent enqueueing) replay a captured chunk of iterations from the third chunk on: one hipGraphLaunch instead
-    // of ~100 launches per iteration.  One stream, no events, no device polling inside the capture; every kernel still
+    // Opt-in (IPM_GRAPH=1, see use_graph): single-stream handles replay a captured chunk of iterations from the third chunk
+    // on: one hipGraphLaunch instead of ~100 launches per iteration.  One stream, no events, no device polling inside the capture; every kernel still
     // tests Scalars::done, so replaying past convergence is the same no-op as enqueueing past it.
     struct GraphGuard { hipGraphExec_t exec = nullptr; ~GraphGuard() { if (exec) (void)hipGraphExecDestroy(exec); } } gg;
     const bool graph_ok = h->use_graph != 0 && h->stream2 == nullptr && h->stream3 == nullptr && h->stream_chain == nullptr && h->nblk > 1;

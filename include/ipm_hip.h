@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IPM_ABI_VERSION 2
+#define IPM_ABI_VERSION 3
 
 /* return codes */
 enum {
@@ -70,7 +70,15 @@ enum {
      * setting by far: the HIP runtime maps streams onto four hardware queues, a mid-size LP keeps only a few CUs busy,
      * and four single-stream solves overlap almost perfectly (4 x DEGEN3: 1.15x the time of one) where two-stream
      * handles share queues and serialise (2.4x).  The batched mode of the Python host sets it. */
-    IPM_FLAG_SINGLE_STREAM = 4
+    IPM_FLAG_SINGLE_STREAM = 4,
+    /* Sparse handles only: factor A D^2 A^T with the multifrontal SPARSE Cholesky (csrc/sparse_chol.h) instead of the
+     * blocked dense one.  What scipy's spsolve does for the reference (SuperLU: fill-reducing order, symbolic
+     * analysis, supernodal numeric factor; main.py:180, :226).  ipm_set_A_csc then analyses the pattern of A A^T in the
+     * row order it is given -- pass the rows in the order ipm_order_rows returns -- and every factorization, forward and
+     * backward substitution is ONE launch that walks the elimination tree.  It pays when the factor stays sparse
+     * (STOCFOR3: 2.2e5 entries, tree height 36, against a chain of 131 dense 128-row blocks); ipm_order_rows reports
+     * the numbers to decide with.  ipm_set_A_csc fails with IPM_ERR_INVALID_ARG when the structures exceed its caps. */
+    IPM_FLAG_SPARSE_FACTOR = 8
 };
 
 typedef struct ipm_handle ipm_handle;
@@ -184,6 +192,20 @@ int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32
  * of a sparse handle is exploited, out[7] = live handles on this device, out[8] = poll time-outs recovered so far,
  * out[9] = 1 when the fused single-workgroup small-LP path serves this handle. */
 int ipm_get_schedule(ipm_handle* h, int32_t out[10]);
+
+/* Fill-reducing order of the ROWS of an m x n sparse A (CSC, host) for the Cholesky of A D^2 A^T: minimum degree on
+ * the pattern of A A^T followed by the elimination-tree postorder.  Pure host code (no device is touched): the
+ * reference gets the same service from SuperLU's COLAMD inside spsolve (main.py:180).  perm[new] = old, length m.
+ * info (may be NULL): [0] entries of the strict lower triangle of A A^T, [1] entries of the Cholesky factor in this
+ * order (diagonal included), [2] multiply-adds of that factorization (sum over columns of count^2), [3] height of the
+ * elimination tree in columns.  Returns IPM_OK; IPM_ERR_WORKSPACE when the pattern or the ordering work exceeds the
+ * built-in caps (A A^T close to dense: keep the dense path), perm is then the identity. */
+int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[4]);
+/* Structure of the sparse factor of a handle created with IPM_FLAG_SPARSE_FACTOR (IPM_ERR_STATE otherwise):
+ * out[0] panels, [1] tasks, [2] panel-tree height, [3] widest front (rows), [4] entries of L stored, [5] entries of the
+ * update matrices, [6] product-list terms of the formation, [7] launches that fell back to one workgroup after a
+ * hand-off time-out. */
+int ipm_get_factor_info(ipm_handle* h, int64_t out[8]);
 
 /* ---- linear-solve seam (main.py:176-182) and kernel-level entry points ------------- */
 /* Solve B z = rhs for a dense SYMMETRIC POSITIVE (SEMI)DEFINITE m x m host matrix by the blocked guarded Cholesky

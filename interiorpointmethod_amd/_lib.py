@@ -18,7 +18,7 @@ EXPORTS = [
     "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
-    "ipm_iterate", "ipm_solve", "ipm_get_history", "ipm_get_schedule", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
+    "ipm_iterate", "ipm_solve", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
     "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps",
 ]
 
@@ -27,7 +27,9 @@ STATUS_RUNNING, STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NAN = 0, 1, 2, 3
 FLAG_NO_DEVICE_POLLING = 1      # include/ipm_hip.h: IPM_FLAG_NO_DEVICE_POLLING
 FLAG_NO_AUTO_REGULARIZE = 2     # include/ipm_hip.h: IPM_FLAG_NO_AUTO_REGULARIZE
 FLAG_SINGLE_STREAM = 4          # include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM
-ABI_VERSION = 2
+FLAG_SPARSE_FACTOR = 8          # include/ipm_hip.h: IPM_FLAG_SPARSE_FACTOR
+ERR_WORKSPACE = -4
+ABI_VERSION = 3
 HISTORY_CAPACITY = 1024         # IPM_HISTORY_CAPACITY
 ERR_INVALID_INPUT = -6
 
@@ -120,6 +122,8 @@ def load():
     lib.ipm_solve.argtypes = [vp, dbl, dbl, dbl, i32, C.POINTER(Stats)]
     lib.ipm_get_history.argtypes = [vp, C.POINTER(IterRecord), i32, C.POINTER(i32)]
     lib.ipm_get_schedule.argtypes = [vp, C.POINTER(i32)]
+    lib.ipm_order_rows.argtypes = [i64, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), pd]
+    lib.ipm_get_factor_info.argtypes = [vp, C.POINTER(i64)]
     lib.ipm_solve_linear.argtypes = [vp, pd, i64, pd, pd, C.POINTER(i32)]
     lib.ipm_normal_solve.argtypes = [vp, pd, pd, pd, C.c_int, C.POINTER(i32)]
     lib.ipm_form_normal_matrix.argtypes = [vp, pd, pd, i64]

@@ -24,6 +24,8 @@
 #include "sparse_ops.h"
 #include "trsv_grouped.h"
 #include "small_lp.h"
+#include "sparse_chol.h"
+#include "sparse_symbolic.h"
 #include "vector_ops.h"
 
 #include <algorithm>
@@ -92,6 +94,20 @@ struct ipm_handle {
     int *sm_bptr = nullptr, *sm_bcol = nullptr;
     unsigned short *sm_bi = nullptr, *sm_bk = nullptr;
     double* sm_bcoef = nullptr;
+    // multifrontal sparse Cholesky (sparse_chol.h), IPM_FLAG_SPARSE_FACTOR: structures built by ipm_set_A_csc, own allocations
+    bool spf = false;                     // the sparse factor serves this handle
+    bool spf_off = false;                 // set around calls that factor a caller's dense matrix (ipm_solve_linear)
+    bool sp_serial = false;               // after a hand-off time-out: one workgroup per launch (never waits)
+    SpFactor spF;                         // device view
+    std::vector<void*> sp_allocs;
+    int *sp_fptr = nullptr, *sp_fcol = nullptr;
+    double* sp_fcoef = nullptr;
+    long long* sp_diagpos = nullptr;
+    long long sp_nslot = 0, sp_nu = 0, sp_terms = 0;
+    int sp_height = 0, sp_rmax = 0, sp_grid = 1, sp_serial_launches = 0, sp_nvirtual = 0;
+    size_t sp_lds_chol = 0, sp_lds_solve = 0;
+    int sp_lds_doubles = 16, sp_threads = 256;
+    unsigned sp_epoch = 0;
     double shift_rel = 0.0;               // Tikhonov shift in effect (opt.regularize, or 1e-14 switched on by ipm_solve)
     int auto_reg = 0;                     // 1: the shift was switched on automatically
     unsigned* d_flags = nullptr;          // [2*nblk] hand-off flags + 1 timeout word (own allocation)
@@ -260,6 +276,7 @@ __global__ void set_params_kernel(Scalars* sc, double e1, double e2, double e3, 
     if (reset) { sc->k = 0; sc->fixed = 0; sc->fixed_first = 0; sc->obj_last_finite = __builtin_nan(""); }
 }
 
+static void free_sparse_factor(ipm_handle* h);
 extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* opts, void* workspace,
                           size_t workspace_bytes, void* stream, ipm_handle** out) {
     if (!out) return fail(nullptr, IPM_ERR_INVALID_ARG, "out is NULL");
@@ -460,6 +477,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->gX) (void)hipFree(h->gX);
     if (h->gS) (void)hipFree(h->gS);
     if (h->gPart) (void)hipFree(h->gPart);
+    free_sparse_factor(h);
     for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
         if (p) (void)hipFree(p);
     if (h->own_ws && h->ws) (void)hipFree(h->ws);
@@ -486,6 +504,228 @@ extern "C" int ipm_set_A_dense(ipm_handle* h, const double* A, int64_t ld, int i
                                 is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->haveA = true; h->predictor_valid = false;
+    return IPM_OK;
+}
+
+// ------------------------------------------------------------------------------- sparse factor (IPM_FLAG_SPARSE_FACTOR)
+static void free_sparse_factor(ipm_handle* h) {
+    for (void* p : h->sp_allocs) if (p) (void)hipFree(p);
+    h->sp_allocs.clear();
+    h->spf = false;
+}
+
+template <class T>
+static int sp_upload(ipm_handle* h, const std::vector<T>& v, T** out, size_t min_count = 1) {
+    const size_t cnt = std::max(v.size(), min_count);
+    void* d = nullptr;
+    HIP_TRY(h, hipMalloc(&d, sizeof(T) * cnt));
+    h->sp_allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(h, hipMemcpyAsync(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, h->stream));
+    *out = (T*)d;
+    return IPM_OK;
+}
+template <class T>
+static int sp_alloc_zero(ipm_handle* h, size_t count, T** out) {
+    void* d = nullptr;
+    if (count < 1) count = 1;
+    HIP_TRY(h, hipMalloc(&d, sizeof(T) * count));
+    h->sp_allocs.push_back(d);
+    HIP_TRY(h, hipMemsetAsync(d, 0, sizeof(T) * count, h->stream));
+    *out = (T*)d;
+    return IPM_OK;
+}
+
+// Symbolic analysis of A A^T in the given row order, task partition, product lists of the formation; everything the three
+// kernels of sparse_chol.h index with goes to the device once.  cp/ri/cv: canonical CSC of A; rp/ci/rv: its CSR.
+static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const std::vector<int>& ri, const std::vector<double>& cv,
+                               const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& rv) {
+    free_sparse_factor(h);
+    const int m = (int)h->m, n = (int)h->n;
+    sym::Pattern P;
+    if (!sym::normal_pattern(m, n, cp.data(), ri.data(), (int64_t)1.5e8, P))
+        return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: the pattern of A A^T exceeds 1.5e8 entries (use the dense path)");
+    sym::Supernodes S;
+    double relax = 1.0;
+    if (const char* e = getenv("IPM_SP_RELAX")) relax = atof(e);
+    const int arc = sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax);
+    if (arc) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: the factor structures exceed 2.5e8 entries (use the dense path)");
+    if (S.rmax > SPC_PANEL || S.panel_max > SPC_PANEL) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: a front of %d rows exceeds the panel budget", S.rmax);
+    const int nsn = S.nsn;
+    // ---- tasks: whole subtrees below a work threshold, chains of the remaining (top) panels
+    std::vector<double> sub((size_t)nsn, 0.0);
+    double total = 0.0;
+    for (int J = 0; J < nsn; ++J) {
+        const double r = (double)(S.rowptr[(size_t)J + 1] - S.rowptr[J]);
+        const double cst = 1.0 + r * r / 1024.0 + 0.5 * (S.childptr[(size_t)J + 1] - S.childptr[J]);
+        sub[J] += cst;
+        total += cst;
+        if (S.parent[J] >= 0) sub[S.parent[J]] += sub[J];
+    }
+    // (every task costs one draw from ONE atomic counter, every workgroup one more: a few hundred of each keep that queue
+    //  off the critical path -- measured: 2048 workgroups drawing 3000 tasks spend 0.2 ms per sweep on the counter alone)
+    const int threads = (getenv("IPM_SP_THREADS") ? atoi(getenv("IPM_SP_THREADS")) : (S.rmax <= 64 ? 64 : SPC_THREADS)) == 64 ? 64 : SPC_THREADS;
+    double div = threads == 64 ? 3072.0 : 1536.0;
+    if (const char* e = getenv("IPM_SP_TASK_DIV")) div = std::max(1.0, atof(e));
+    const double T = std::max(8.0, total / div);
+    std::vector<int> taskof((size_t)nsn, -1), topkids((size_t)nsn, 0);
+    for (int J = 0; J < nsn; ++J) if (sub[J] > T && S.parent[J] >= 0) topkids[S.parent[J]]++;
+    int ntask = 0;
+    for (int J = nsn - 1; J >= 0; --J) {
+        const int pj = S.parent[J];
+        const bool low = !(sub[J] > T);
+        if (low) taskof[J] = (pj >= 0 && !(sub[pj] > T)) ? taskof[pj] : ntask++;
+        else taskof[J] = (pj >= 0 && topkids[pj] == 1) ? taskof[pj] : ntask++;       // (the parent of a top panel is a top panel)
+    }
+    // tasks in ascending order of their top panel: ids were handed out top-down, so reverse them
+    for (int J = 0; J < nsn; ++J) taskof[J] = ntask - 1 - taskof[J];
+    std::vector<int> taskptr((size_t)ntask + 1, 0), tasknode((size_t)nsn);
+    for (int J = 0; J < nsn; ++J) taskptr[(size_t)taskof[J] + 1]++;
+    for (int t = 0; t < ntask; ++t) taskptr[(size_t)t + 1] += taskptr[t];
+    { std::vector<int> nx(taskptr.begin(), taskptr.end() - 1); for (int J = 0; J < nsn; ++J) tasknode[(size_t)nx[taskof[J]]++] = J; }
+    for (int t = 0; t + 1 < ntask; ++t)              // the order the deadlock argument rests on
+        if (tasknode[(size_t)taskptr[t + 1] - 1] >= tasknode[(size_t)taskptr[t + 2] - 1])
+            return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: internal error (task order)");
+    std::vector<SpNode> nodes((size_t)nsn);
+    for (int J = 0; J < nsn; ++J) {
+        SpNode& nd = nodes[J];
+        memset(&nd, 0, sizeof nd);
+        nd.c0 = S.c0[J]; nd.w = S.w[J];
+        nd.r = (int)(S.rowptr[(size_t)J + 1] - S.rowptr[J]);
+        nd.nchild = S.childptr[(size_t)J + 1] - S.childptr[J]; nd.child0 = S.childptr[J];
+        nd.parent = S.parent[J];
+        nd.publish = (nd.parent >= 0 && taskof[nd.parent] != taskof[J]) ? 1 : 0;
+        for (int t = S.childptr[J]; t < S.childptr[(size_t)J + 1]; ++t) if (taskof[S.child[(size_t)t]] != taskof[J]) nd.wait_children = 1;
+        nd.rowptr = S.rowptr[J]; nd.lptr = S.lptr[J]; nd.uptr = S.uptr[J];
+    }
+    if (S.max_children > SPC_MAXCH) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: internal error (fan-in)");
+    std::vector<SpRec> recs((size_t)nsn);
+    for (int tn = 0; tn < nsn; ++tn) {
+        const int J = tasknode[(size_t)tn];
+        const SpNode& nd = nodes[J];
+        SpRec& rc = recs[(size_t)tn];
+        memset(&rc, 0, sizeof rc);
+        rc.J = J; rc.c0 = nd.c0; rc.w = nd.w; rc.r = nd.r; rc.nchild = nd.nchild; rc.parent = nd.parent;
+        rc.wait_children = nd.wait_children; rc.publish = nd.publish;
+        rc.rowptr = nd.rowptr; rc.lptr = nd.lptr; rc.uptr = nd.uptr;
+        for (int t = 0; t < nd.nchild; ++t) {
+            const int K = S.child[(size_t)(nd.child0 + t)];
+            SpChild& c = rc.ch[t];
+            c.uptr = nodes[K].uptr; c.relptr = nodes[K].rowptr + nodes[K].w; c.pc = nodes[K].r - nodes[K].w; c.K = K;
+            c.ext = taskof[K] != taskof[J] ? 1 : 0;
+        }
+    }
+    // ---- product lists: slot e of the panel values <- sum_t fcoef[t] d[fcol[t]]
+    const int64_t nslot = S.lptr[nsn];
+    std::vector<int> fptr((size_t)nslot + 1, 0), fcol;
+    std::vector<double> fcoef;
+    {
+        size_t terms = 0;
+        for (int j = 0; j < n; ++j) { const size_t c = (size_t)(cp[j + 1] - cp[j]); terms += c * (c + 1) / 2; }
+        if (terms > ((size_t)1 << 30)) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: %zu products in A D^2 A^T (use the dense path)", terms);
+        fcol.resize(terms); fcoef.resize(terms);
+        std::vector<int> where((size_t)m, -1);
+        // pass 1: counts per slot, pass 2: fill (columns ascending within a slot)
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<int> nx;
+            if (pass == 1) {
+                for (int64_t e = 0; e < nslot; ++e) fptr[(size_t)e + 1] += fptr[(size_t)e];
+                nx.assign(fptr.begin(), fptr.end() - 1);
+            }
+            for (int J = 0; J < nsn; ++J) {
+                const int64_t r0 = S.rowptr[J];
+                const int r = nodes[J].r, w = nodes[J].w, c0 = nodes[J].c0;
+                for (int a = 0; a < r; ++a) where[S.rows[(size_t)(r0 + a)]] = a;
+                for (int b = 0; b < w; ++b) {
+                    const int k = c0 + b;
+                    for (int p = rp[k]; p < rp[k + 1]; ++p) {                    // columns of A ascending
+                        const int j = ci[p];
+                        const double akj = rv[p];
+                        for (int q = cp[j]; q < cp[j + 1]; ++q) {
+                            const int i = ri[q];
+                            if (i < k) continue;
+                            const int a = where[i];
+                            if (a < 0) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: internal error (entry outside the front)");
+                            const int64_t e = S.lptr[J] + (int64_t)a * w + b;
+                            if (pass == 0) fptr[(size_t)e + 1]++;
+                            else { const int t = nx[(size_t)e]++; fcol[(size_t)t] = j; fcoef[(size_t)t] = cv[q] * akj; }
+                        }
+                    }
+                }
+                for (int a = 0; a < r; ++a) where[S.rows[(size_t)(r0 + a)]] = -1;
+            }
+        }
+        h->sp_terms = (long long)terms;
+    }
+    // ---- upload
+    SpFactor& F = h->spF;
+    memset(&F, 0, sizeof F);
+    F.nsn = nsn; F.ntask = ntask; F.m = m;
+    int rc;
+    SpNode* d_node = nullptr; int *d_rows = nullptr, *d_child = nullptr, *d_crel = nullptr, *d_taskptr = nullptr, *d_tasknode = nullptr, *d_taskof = nullptr;
+    SpRec* d_rec = nullptr;
+    if ((rc = sp_upload(h, recs, &d_rec))) return rc;
+    F.rec = d_rec;
+    if ((rc = sp_upload(h, nodes, &d_node))) return rc;
+    if ((rc = sp_upload(h, S.rows, &d_rows))) return rc;
+    if ((rc = sp_upload(h, S.child, &d_child))) return rc;
+    if ((rc = sp_upload(h, S.crel, &d_crel))) return rc;
+    if ((rc = sp_upload(h, taskptr, &d_taskptr))) return rc;
+    if ((rc = sp_upload(h, tasknode, &d_tasknode))) return rc;
+    if ((rc = sp_upload(h, taskof, &d_taskof))) return rc;
+    if ((rc = sp_upload(h, fptr, &h->sp_fptr))) return rc;
+    if ((rc = sp_upload(h, fcol, &h->sp_fcol))) return rc;
+    if ((rc = sp_upload(h, fcoef, &h->sp_fcoef))) return rc;
+    { std::vector<long long> dp(S.diagpos.begin(), S.diagpos.end()); if ((rc = sp_upload(h, dp, &h->sp_diagpos))) return rc; }
+    F.node = d_node; F.rows = d_rows; F.child = d_child; F.crel = d_crel; F.taskptr = d_taskptr; F.tasknode = d_tasknode; F.taskof = d_taskof;
+    if ((rc = sp_alloc_zero(h, (size_t)nslot, &F.L))) return rc;
+    if ((rc = sp_alloc_zero(h, (size_t)S.uptr[nsn], &F.U))) return rc;
+    if ((rc = sp_alloc_zero(h, S.rows.size(), &F.uvec))) return rc;
+    if ((rc = sp_alloc_zero(h, (size_t)3 * nsn, &F.flag))) return rc;
+    if ((rc = sp_alloc_zero(h, (size_t)8, &F.ctr))) return rc;
+    F.timeout = h->d_flags + 2 * (size_t)h->nblk;
+    F.done = &h->sc->done;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->sp_nslot = nslot; h->sp_nu = S.uptr[nsn]; h->sp_height = S.height; h->sp_rmax = S.rmax; h->sp_nvirtual = S.nvirtual;
+    h->sp_lds_doubles = (int)std::max<int64_t>(std::max<int64_t>(16, S.panel_max), std::min<int64_t>((int64_t)S.rmax * S.rmax, SPC_FRONT));
+    if (const char* e = getenv("IPM_SP_FRONT")) h->sp_lds_doubles = (int)std::max<int64_t>(std::max<int64_t>(16, S.panel_max), std::min<int64_t>((int64_t)S.rmax * S.rmax, atoi(e)));
+    h->sp_lds_chol = sizeof(double) * (size_t)h->sp_lds_doubles;
+    h->sp_lds_solve = sizeof(double) * ((size_t)std::max(16, S.rmax) + SPC_WCAP * SPC_WCAP);
+    h->sp_threads = threads;
+    {   // workgroups the chip holds at once: LDS- or wave-limited (32 waves per CU)
+        const size_t lds = std::max(h->sp_lds_chol, h->sp_lds_solve) + 512;
+        const int wave_cap = threads == 64 ? 16 : 8;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)wave_cap, (size_t)(160 * 1024) / lds));
+        h->sp_grid = std::max(1, std::min(ntask, 256 * per_cu));
+    }
+    if (const char* e = getenv("IPM_SP_GRID")) h->sp_grid = std::max(1, std::min(ntask, atoi(e)));
+    h->sp_epoch = 0; h->sp_serial = false;
+    h->spf = true;
+    return IPM_OK;
+}
+
+extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[4]) {
+    if (m <= 0 || n <= 0 || !colptr || !rowind || !perm || m > (1 << 24)) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: bad arguments");
+    for (int64_t i = 0; i < m; ++i) perm[i] = (int32_t)i;
+    if (info) info[0] = info[1] = info[2] = info[3] = 0.0;
+    if (colptr[0] != 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: colptr[0] != 0");
+    for (int64_t j = 0; j < n; ++j) {
+        if (colptr[j + 1] < colptr[j]) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: colptr not monotone");
+        for (int32_t p = colptr[j]; p < colptr[j + 1]; ++p)
+            if (rowind[p] < 0 || rowind[p] >= m) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: row index %d out of range", rowind[p]);
+    }
+    std::vector<int> pv;
+    sym::OrderInfo oi;
+    if (sym::order_rows((int)m, (int)n, colptr, rowind, pv, oi)) return fail(nullptr, IPM_ERR_WORKSPACE, "ipm_order_rows: A A^T is too dense for the sparse factor");
+    for (int64_t i = 0; i < m; ++i) perm[i] = pv[(size_t)i];
+    if (info) { info[0] = (double)oi.nnz_pattern; info[1] = (double)oi.nnz_factor; info[2] = oi.flops; info[3] = (double)oi.height; }
+    return IPM_OK;
+}
+
+extern "C" int ipm_get_factor_info(ipm_handle* h, int64_t out[8]) {
+    if (!h || !out) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_factor_info: bad arguments");
+    if (!h->spf) return fail(h, IPM_ERR_STATE, "ipm_get_factor_info: the handle has no sparse factor (IPM_FLAG_SPARSE_FACTOR)");
+    out[0] = h->spF.nsn; out[1] = h->spF.ntask; out[2] = h->sp_height; out[3] = h->sp_rmax; out[4] = h->sp_nslot; out[5] = h->sp_nu;
+    out[6] = h->sp_terms; out[7] = h->sp_serial_launches;
     return IPM_OK;
 }
 
@@ -631,6 +871,10 @@ extern "C" int ipm_set_A_csc(ipm_handle* h, const int32_t* colptr, const int32_t
                 //  be capturing a graph on a blocking stream, which a NULL-stream copy would illegally depend on)
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
             }
+        }
+        if ((h->opt.flags & IPM_FLAG_SPARSE_FACTOR) && !h->small) {      // (m <= 128: the fused single-workgroup kernel serves the LP)
+            int rc = build_sparse_factor(h, cp, ri, cv, rp, ci, rv);
+            if (rc) { h->haveA = false; return rc; }
         }
         return IPM_OK;
     }
@@ -780,8 +1024,23 @@ static bool overlap_residuals(const ipm_handle* h) {
     return h->stream3 != nullptr && h->profiling < 2;          // (created for dense handles from 16 blocks on, ipm_create)
 }
 
+static inline bool sp_on(const ipm_handle* h) { return h->spf && !h->spf_off; }
+static inline unsigned sp_launch_grid(ipm_handle* h) {
+    if (h->sp_serial) { ++h->sp_serial_launches; return 1u; }
+    return (unsigned)h->sp_grid;
+}
+
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
-static int enqueue_form(ipm_handle* h, const double* d) {
+static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false) {
+    if (sp_on(h) && !dense_image) {
+        // the entries of B go straight into the panels of the sparse factor (one thread per slot, fixed term order)
+        hipLaunchKernelGGL(sp_form_kernel, dim3((unsigned)((h->sp_nslot + 255) / 256)), dim3(256), 0, h->stream, h->sp_fptr, h->sp_fcol,
+                           h->sp_fcoef, h->sp_nslot, d, h->spF.L, &h->sc->done);
+        hipLaunchKernelGGL(sp_maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->spF.L, h->sp_diagpos, (int)h->m, &h->sc->maxdiag,
+                           &h->sc->done);
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
     if (h->sparse && h->list_form) {
         const int64_t nB = h->mp * h->mp;                       // even (mp is a multiple of 128)
         hipLaunchKernelGGL(zero_unless_done_kernel, dim3((unsigned)std::min<int64_t>((nB / 2 + 255) / 256, 4096)), dim3(256), 0, h->stream,
@@ -832,6 +1091,16 @@ static int enqueue_form(ipm_handle* h, const double* d) {
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
 static int enqueue_group_inverses(ipm_handle* h, int g0, int g1, hipStream_t st);
 static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1, int ginv_step = -1) {
+    if (sp_on(h)) {                     // multifrontal sparse Cholesky: one launch walks the elimination tree
+        if (h->sp_threads == 64)
+            hipLaunchKernelGGL(sp_chol_kernel<64>, dim3(sp_launch_grid(h)), dim3(64), h->sp_lds_chol, h->stream, h->spF, ++h->sp_epoch, &h->sc->maxdiag,
+                               h->opt.pivot_guard_eps, h->opt.pivot_guard_big, h->shift_rel, &h->sc->fixed, h->sp_lds_doubles);
+        else
+            hipLaunchKernelGGL(sp_chol_kernel<SPC_THREADS>, dim3(sp_launch_grid(h)), dim3(SPC_THREADS), h->sp_lds_chol, h->stream, h->spF, ++h->sp_epoch, &h->sc->maxdiag,
+                               h->opt.pivot_guard_eps, h->opt.pivot_guard_big, h->shift_rel, &h->sc->fixed, h->sp_lds_doubles);
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
     const int* done = &h->sc->done;
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
@@ -1021,6 +1290,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
 // recursive doubling 128 -> 256 -> 512 -> 1024, three GEMMs per level batched over (pairs in a group,
 // groups).  After enqueue_factor, on the main stream.
 static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStream_t st = nullptr) {
+    if (sp_on(h)) return IPM_OK;
     if (!h->grouped_trsv) return IPM_OK;
     const int GS = h->gsz;
     const int64_t GR = (int64_t)GS * 128;
@@ -1106,6 +1376,18 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out, hipEvent
 
 // out = B^{-1} r  (r is consumed; uses t2 as the intermediate)
 static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_last = nullptr) {
+    if (sp_on(h)) {                     // forward and backward sweep over the elimination tree, one launch each
+        const int rm = std::max(16, h->sp_rmax);
+        if (h->sp_threads == 64) {
+            hipLaunchKernelGGL(sp_fwd_kernel<64>, dim3(sp_launch_grid(h)), dim3(64), h->sp_lds_solve, h->stream, h->spF, ++h->sp_epoch, r, h->t2, rm);
+            hipLaunchKernelGGL(sp_bwd_kernel<64>, dim3(sp_launch_grid(h)), dim3(64), 0, h->stream, h->spF, ++h->sp_epoch, h->t2, out);
+        } else {
+            hipLaunchKernelGGL(sp_fwd_kernel<SPC_THREADS>, dim3(sp_launch_grid(h)), dim3(SPC_THREADS), h->sp_lds_solve, h->stream, h->spF, ++h->sp_epoch, r, h->t2, rm);
+            hipLaunchKernelGGL(sp_bwd_kernel<SPC_THREADS>, dim3(sp_launch_grid(h)), dim3(SPC_THREADS), 0, h->stream, h->spF, ++h->sp_epoch, h->t2, out);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
     if (h->grouped_trsv) return enqueue_potrs_grouped(h, r, out, wait_last);
     if (wait_last) HIP_TRY(h, hipStreamWaitEvent(h->stream, wait_last, 0));
     if (h->persistent_trsv && h->nblk >= 2 && h->nblk <= 240) {
@@ -1250,6 +1532,7 @@ static int read_scalars(ipm_handle* h, bool* timed_out = nullptr) {
 // garbage but nothing hung.  Policy: never surface it -- switch this handle to stream events for good, undo the
 // call's effect on the iterate (callers restore their snapshot) and run it again.
 static void poll_fallback(ipm_handle* h) {
+    if (h->spf) h->sp_serial = true;          // sparse factor: one workgroup per launch from now on (it never waits)
     h->flag_sync = 0;
     ++h->timeouts_recovered;
 }
@@ -1279,7 +1562,7 @@ static int enqueue_snapshot(ipm_handle* h, int restore) {
     return IPM_OK;
 }
 // can the next factorization time out at all?  (mirrors the `fs` rule of enqueue_factor)
-static bool may_poll(const ipm_handle* h) { return h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
+static bool may_poll(const ipm_handle* h) { return (h->spf && !h->sp_serial) || h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
 
 static void fill_stats(ipm_handle* h, ipm_stats* st, double ms) {
     if (!st) return;
@@ -1481,7 +1764,7 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     // on: one hipGraphLaunch instead of ~100 launches per iteration.  One stream, no events, no device polling inside the capture; every kernel still
     // tests Scalars::done, so replaying past convergence is the same no-op as enqueueing past it.
     struct GraphGuard { hipGraphExec_t exec = nullptr; ~GraphGuard() { if (exec) (void)hipGraphExecDestroy(exec); } } gg;
-    const bool graph_ok = h->use_graph != 0 && h->stream2 == nullptr && h->stream3 == nullptr && h->stream_chain == nullptr && h->nblk > 1;
+    const bool graph_ok = h->use_graph != 0 && !h->spf && h->stream2 == nullptr && h->stream3 == nullptr && h->stream_chain == nullptr && h->nblk > 1;
     int chunk_idx = 0;
     for (;;) {
         // roll-back point: the first chunk (auto-regularize restart) and every chunk that can hit a poll time-out
@@ -1572,7 +1855,7 @@ extern "C" int ipm_form_normal_matrix(ipm_handle* h, const double* d, double* B,
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 0);
     HIP_TRY(h, hipMemcpyAsync(h->d, d, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
-    int rc = enqueue_form(h, h->d);
+    int rc = enqueue_form(h, h->d, /*dense_image=*/true);
     if (rc) return rc;
     std::vector<double> tmp((size_t)h->mp * h->mp);
     HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->B, sizeof(double) * h->mp * h->mp, hipMemcpyDeviceToHost, h->stream));
@@ -1622,6 +1905,11 @@ extern "C" int ipm_normal_solve(ipm_handle* h, const double* d, const double* rh
 extern "C" int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl) {
     if (!h || !L || ldl < h->m) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_factor: bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->spf) {                       // dense image of the sparse factor (the dense B buffer is free in this mode)
+        HIP_TRY(h, hipMemsetAsync(h->B, 0, sizeof(double) * h->mp * h->mp, h->stream));
+        hipLaunchKernelGGL(sp_expand_kernel, dim3((unsigned)h->spF.nsn), dim3(256), 0, h->stream, h->spF, h->B, (long long)h->mp);
+        HIP_TRY(h, hipGetLastError());
+    }
     std::vector<double> tmp((size_t)h->mp * h->mp);
     HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->B, sizeof(double) * h->mp * h->mp, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1641,6 +1929,8 @@ extern "C" int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, con
     }
     const bool saved_env = h->use_env;
     h->use_env = false;                                   // an arbitrary dense B: no structure to exploit
+    struct SpOff { ipm_handle* h; ~SpOff() { h->spf_off = false; } } sp_off{h};
+    h->spf_off = true;                                    // ... and not the sparse factor of the handle's own A
     int rc = IPM_OK;
     for (int attempt = 0;; ++attempt) {                   // second pass only after a recovered poll time-out
         hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, h->stream, h->sc, 1e-8, 1e-8, 1e-8, h->opt.eta, 1 << 30, 1, 1);

@@ -67,6 +67,50 @@ def envelope_row_order(A, force=False):
     return None
 
 
+def sparse_factor_order(A):
+    """Fill-reducing row order for the multifrontal sparse Cholesky (ipm_order_rows: minimum degree + elimination-tree
+    postorder, host only) -> (perm, info) with info = dict(nnz_pattern, nnz_factor, flops, height), or (None, None)
+    when A A^T is too dense for it.  The reference gets this from SuperLU's COLAMD inside spsolve (main.py:180)."""
+    lib = _lib.load()
+    A = _sp.csc_matrix(A)
+    m, n = A.shape
+    perm = np.zeros(m, dtype=np.int32)
+    info = np.zeros(4)
+    ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ii = np.ascontiguousarray(A.indices, dtype=np.int32)
+    rc = lib.ipm_order_rows(m, n, ip.ctypes.data_as(C.POINTER(C.c_int32)), ii.ctypes.data_as(C.POINTER(C.c_int32)),
+                            perm.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(info))
+    if rc == _lib.ERR_WORKSPACE:
+        return None, None
+    _lib.check(None, rc)
+    return perm.astype(np.int64), dict(nnz_pattern=int(info[0]), nnz_factor=int(info[1]), flops=float(info[2]),
+                                       height=int(info[3]))
+
+
+SPARSE_FACTOR_MIN_ROWS = 600          # below five 128-row blocks the dense chain is shorter than one tree sweep set
+
+
+def prefer_sparse_factor(m, info, dense_blocks):
+    """The rule of factor="auto", fitted to measurements on MI355X (tools/sparse_factor_check.py, ms per iteration,
+    sparse / dense): STOCFOR3 1.2 / 14.0, SIERRA 0.65 / 2.2, STOCFOR2 0.51 / 1.47, CZPROB 0.60 / 0.92, SCTAP3 0.59 / 0.92,
+    SHELL 0.49 / 0.67, 80BAU3B 2.6 / 3.35, GANGES 1.03 / 1.11 -- but 25FV47 1.34 / 0.70, GREENBEA 3.0 / 1.7, BNL2 4.4 / 1.6,
+    D2Q06C 6.4 / 1.6, PILOTNOV 3.3 / 0.9: the sparse factor walks the elimination tree five times per iteration with scalar
+    fp64 work proportional to info["flops"]; the dense-tile path walks a chain of m/128 pivot blocks and does its flops
+    on the matrix cores.  Sparse wins where the factor is genuinely sparse."""
+    if info is None or m < SPARSE_FACTOR_MIN_ROWS:
+        return False
+    t_sparse = 0.45 + info["flops"] / 3.0e6 + 0.004 * info["height"]     # ms per iteration (GROW22: 1320 rows, tree height 900)
+    t_dense = 0.1 + 0.08 * dense_blocks
+    return t_sparse < t_dense
+
+
+def _worth_ordering(A):
+    """Cheap screen before the minimum-degree ordering: an upper bound on the entries of A A^T (sum over columns of
+    c (c - 1) / 2).  Beyond a few million the factor is close to dense and the ordering would only burn host time."""
+    c = np.diff(A.indptr).astype(np.float64)
+    return float(np.sum(c * (c - 1.0) / 2.0)) <= 4.0e6
+
+
 def factor_flops(A, nb=128):
     """Flops of the blocked Cholesky of A A^T AS THE DEVICE RUNS IT for this A: dense handles and sparse handles whose
     tile envelope removes less than 20 % of the work factor the full matrix (m^3/3); otherwise only the blocks inside
@@ -105,7 +149,7 @@ class IpmSolver:
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
                  check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto", concurrent=False,
-                 auto_regularize=True):
+                 auto_regularize=True, factor=None):
         lib = _lib.load()
         self._lib = lib
         self._h = None
@@ -126,7 +170,27 @@ class IpmSolver:
         b = _col(b, self.m, "b")
         c = _col(c, self.n, "c")
         self._host = (A, b, c)      # caller's row order: used by start-point heuristics only
-        if _sp is not None and _sp.issparse(A) and reorder and (reorder == "rcm" or self.m >= REORDER_MIN_ROWS):
+        # factor: "dense" = blocked dense-tile Cholesky (tile envelope, RCM row order), "sparse" = multifrontal sparse
+        # Cholesky (minimum-degree row order), "auto" (default; environment IPM_FACTOR overrides) = whichever the model
+        # of prefer_sparse_factor expects to be faster
+        factor = factor or os.environ.get("IPM_FACTOR", "auto")
+        if factor not in ("auto", "dense", "sparse"):
+            raise ValueError("factor must be 'auto', 'dense' or 'sparse'")
+        self.factor = "dense"
+        self.order_info = None
+        if _sp is not None and _sp.issparse(A) and factor != "dense" and \
+                (factor == "sparse" or (self.m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(A))):
+            perm, info = sparse_factor_order(A)
+            if perm is not None and (factor == "sparse" or prefer_sparse_factor(self.m, info, (self.m + 127) // 128)):
+                self.factor, self.order_info = "sparse", info
+                self._perm = perm
+                A = _sp.csc_matrix(_sp.csr_matrix(A)[perm])
+                A.sort_indices()
+                b = np.ascontiguousarray(b[perm])
+            elif factor == "sparse":
+                raise ValueError("factor='sparse': A A^T is too dense for the sparse factor (ipm_order_rows)")
+        if self.factor == "dense" and _sp is not None and _sp.issparse(A) and reorder and \
+                (reorder == "rcm" or self.m >= REORDER_MIN_ROWS):
             perm = envelope_row_order(A, force=(reorder == "rcm"))     # "auto": only when it pays
             if perm is not None:
                 self._perm = perm
@@ -142,7 +206,8 @@ class IpmSolver:
         # device polling (include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM).  Without it the library still protects itself (it
         # counts the live handles per device and falls back to stream events).
         opts.flags = ((_lib.FLAG_NO_DEVICE_POLLING | _lib.FLAG_SINGLE_STREAM) if concurrent else 0) | \
-                     (0 if auto_regularize else _lib.FLAG_NO_AUTO_REGULARIZE)
+                     (0 if auto_regularize else _lib.FLAG_NO_AUTO_REGULARIZE) | \
+                     (_lib.FLAG_SPARSE_FACTOR if self.factor == "sparse" else 0)
         nbytes = C.c_size_t(0)
         self.sparse = _sp is not None and _sp.issparse(A)
         if self.sparse:                      # A stays sparse on the device (CSR + CSC, sparse formation of B)
@@ -261,6 +326,16 @@ class IpmSolver:
                 "live_handles", "timeouts_recovered", "fused_small")
         return dict(zip(keys, (int(v) for v in out)))
 
+    def factor_info(self):
+        """Structure of the sparse factor (ipm_get_factor_info) or None for the dense-tile path."""
+        if self.factor != "sparse":
+            return None
+        out = (C.c_int64 * 8)()
+        self._check(self._lib.ipm_get_factor_info(self._h, out))
+        keys = ("panels", "tasks", "height", "widest_front", "factor_entries", "update_entries", "product_terms",
+                "serial_launches")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def set_profiling(self, level=2):
         """0 off, 1 time the A D^2 A^T kernel only, 2 all phases (True == 2 for old callers)."""
         level = 2 if level is True else (0 if level is False else int(level))
@@ -319,8 +394,8 @@ class IpmSolver:
         return x, np.asarray(y).ravel(), s
 
     def solve_linear(self, B, rhs):
-        if self._perm is not None:
-            raise ValueError("solve_linear on a handle with reordered rows: create the solver with reorder=None")
+        """B z = rhs for the CALLER's dense SPD matrix (main.py:176-182): the row order this handle keeps its own A in
+        plays no part (ipm_solve_linear factors B as given, without the tile envelope or the sparse factor)."""
         B = np.ascontiguousarray(np.asarray(B, dtype=np.float64))
         rhs = _col(rhs, self.m, "rhs")
         z = np.empty(self.m)

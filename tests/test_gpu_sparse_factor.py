@@ -1,0 +1,173 @@
+"""GPU tests (-m gpu) of the multifrontal SPARSE Cholesky (csrc/sparse_chol.h, IPM_FLAG_SPARSE_FACTOR):
+what scipy's spsolve (SuperLU) does for the reference at main.py:180 / :226.  Checked against the C++ restatement
+oracle/sparse_chol_oracle.cpp (same symbolic structures, sequential arithmetic), dense LAPACK, the reference's golden
+direction vectors and end-to-end objectives.  fp64; kernel-level bounds next to each assert, 1e-6 relative end to end."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+from scipy import sparse
+
+pytestmark = pytest.mark.gpu
+
+import interiorpointmethod_amd as ipm                      # noqa: E402
+from interiorpointmethod_amd.matio import load_npz_problem  # noqa: E402
+from oracle import ipm_oracle as O                          # noqa: E402
+from oracle import sparse_chol as SO                        # noqa: E402
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+def _lp(golden_dir, name):
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(golden_dir, "netlib", name + ".npz"))
+    return sparse.csc_matrix(A, dtype=np.float64), b, c
+
+
+@pytest.mark.parametrize("name", ["SC205", "BANDM", "SCTAP1", "CZPROB", "STOCFOR2", "25FV47"])
+def test_factor_and_solve_against_oracle_and_lapack(golden_dir, name):
+    """One factorization + solve of A D A^T: the device factor equals the oracle's (same panels, same order of additions up
+    to the pivot-scaling form), L L^T = B, B z = rhs; a second call repeats bit for bit (no atomics on data)."""
+    A, b, c = _lp(golden_dir, name)
+    rng = np.random.default_rng(5)
+    d = rng.uniform(0.5, 2.0, A.shape[1])
+    rhs = rng.standard_normal(A.shape[0])
+    ora = SO.factor_solve(A, d, rhs)
+    B = (A @ sparse.diags(d) @ A.T).toarray()
+    with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
+        assert sv.factor == "sparse" and np.array_equal(sv._perm, ora["perm"])
+        fi = sv.factor_info()
+        z = sv.normal_solve(rhs, d=d)
+        fixed = sv.last_pivots_fixed
+        L = sv.get_factor()
+        z2 = sv.normal_solve(rhs, d=d)
+        Bdev = sv.form_normal_matrix(d)                      # the dense image is still available on such a handle
+    assert fi["panels"] == int(ora["stats"]["panels"]) and fi["height"] == int(ora["stats"]["height"])
+    assert fi["widest_front"] == int(ora["stats"]["widest_front"]) and fi["serial_launches"] == 0
+    assert fixed == ora["fixed"]
+    if fixed == 0:
+        Bp = B[np.ix_(ora["perm"], ora["perm"])]
+        assert np.abs(L @ L.T - Bp).max() <= 1e-13 * np.abs(Bp).max()
+        assert rel(L, ora["L"]) < 1e-11
+        assert rel(L, sla.cholesky(Bp, lower=True)) < 1e-9
+        zref = np.linalg.solve(B, rhs)
+        assert np.linalg.norm(z.ravel() - zref) <= 1e-9 * np.linalg.norm(zref)
+    else:                                                    # 25FV47: one dependent row, guarded on both sides
+        good = np.abs(np.diag(ora["L"])) < 1e30
+        assert np.array_equal(np.abs(np.diag(L)) < 1e30, good)
+        assert np.allclose(np.diag(L)[good], np.diag(ora["L"])[good], rtol=1e-9)
+    assert rel(z.ravel(), ora["z"]) < 1e-8
+    assert np.array_equal(z, z2)
+    assert rel(Bdev, B) < 1e-13
+
+
+def test_guard_and_shift_match_the_oracle(golden_dir):
+    A, b, c = _lp(golden_dir, "SC205")
+    A2 = sparse.vstack([A, A[:4]]).tocsc()                    # four dependent rows
+    m2 = A2.shape[0]
+    rhs = np.linspace(-1.0, 1.0, m2)
+    ora = SO.factor_solve(A2, np.ones(A2.shape[1]), rhs, eps=1e-12)
+    with ipm.IpmSolver(A2, np.zeros(m2), c, factor="sparse", pivot_guard_eps=1e-12) as sv:
+        z = sv.normal_solve(rhs)
+        assert sv.last_pivots_fixed == ora["fixed"] == 4
+    assert np.all(np.isfinite(z)) and rel(z.ravel(), ora["z"]) < 1e-7
+    ora = SO.factor_solve(A2, np.ones(A2.shape[1]), rhs, shift_rel=1e-8)
+    with ipm.IpmSolver(A2, np.zeros(m2), c, factor="sparse", regularize=1e-8) as sv:
+        z = sv.normal_solve(rhs)
+        assert sv.last_pivots_fixed == ora["fixed"] == 0
+    assert rel(z.ravel(), ora["z"]) < 1e-6
+
+
+def test_schedule_independence(golden_dir, monkeypatch):
+    """One workgroup walking the tasks in order (what the library falls back to after a hand-off time-out), a handful, and
+    the full grid give the SAME bits: every sum has a fixed order, whatever the schedule."""
+    A, b, c = _lp(golden_dir, "STOCFOR2")
+    rhs = np.cos(np.arange(A.shape[0]))
+    out = []
+    for grid in ("1", "7", None):
+        if grid is None:
+            monkeypatch.delenv("IPM_SP_GRID", raising=False)
+        else:
+            monkeypatch.setenv("IPM_SP_GRID", grid)
+        with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
+            out.append((sv.normal_solve(rhs), sv.get_factor()))
+    for z, L in out[1:]:
+        assert np.array_equal(z, out[0][0]) and np.array_equal(L, out[0][1])
+
+
+def test_direction_seam_on_the_sparse_factor(golden_dir):
+    """The reference's own predictor / corrector vectors (kat_BANDM.npz, generated from main.py:197-269) through the sparse
+    factor, same bounds as test_gpu_parity.py::test_direction_kats."""
+    z = np.load(os.path.join(golden_dir, "kat_BANDM.npz"))
+    m, n = (int(v) for v in z["shape"])
+    A = sparse.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=(m, n))
+    with ipm.IpmSolver(A, z["b"], z["c"], factor="sparse") as sv:
+        pre = "k0_"
+        sv.set_state(z[pre + "x"], z[pre + "y"], z[pre + "s"])
+        dxa, dya, dsa = sv.newton_direction(False)
+        assert rel(dxa, z[pre + "dxa"]) < 1e-11 and rel(dya, z[pre + "dya"]) < 1e-11 and rel(dsa, z[pre + "dsa"]) < 1e-11
+        dx, dy, ds = sv.newton_direction(True)
+        assert rel(dx, z[pre + "dx"]) < 1e-10 and rel(dy, z[pre + "dy"]) < 1e-10 and rel(ds, z[pre + "ds"]) < 1e-10
+        sv.set_state(z[pre + "x"], z[pre + "y"], z[pre + "s"])
+        st = sv.iterate(1)
+        xn, yn, sn = sv.get_state()
+        assert np.isclose(st["alpha_p"], float(z[pre + "alpha_p"]), rtol=1e-9)
+        assert rel(xn, z[pre + "xn"]) < 1e-10 and rel(yn, z[pre + "yn"]) < 1e-10 and rel(sn, z[pre + "sn"]) < 1e-10
+        pre = "k%d_" % int(z["iters"][1])
+        sv.set_state(z[pre + "x"], z[pre + "y"], z[pre + "s"])
+        dxa, dya, dsa = sv.newton_direction(False)
+        assert rel(dya, z[pre + "dya"]) < 1e-8 and rel(dsa, z[pre + "dsa"]) < 1e-8 and rel(dxa, z[pre + "dxa"]) < 1e-8
+
+
+SPARSE_PARITY = ["SC205", "BANDM", "SCTAP1", "SCTAP2", "SCTAP3", "SCSD8", "GROW7", "GROW15", "STOCFOR2", "STOCFOR3", "E226", "WOODW"]
+
+
+@pytest.mark.parametrize("name", SPARSE_PARITY)
+def test_netlib_parity_forced_sparse_factor(golden_dir, name):
+    """Parity LPs of BASELINE.md 2.4 with the sparse factor forced: the reference's objective (e2e_*.npz, verbatim loop) to
+    1e-6 relative, its stop test satisfied on the host, the iteration count within 2."""
+    e = np.load(os.path.join(golden_dir, "e2e_%s.npz" % name))
+    A, b, c = _lp(golden_dir, name)
+    x, y, s, info = ipm.solve_with_info(A, b, c, tol=1e-8, y0=1.0, max_iter=5000, factor="sparse")
+    ref = float(e["objective"])
+    assert info["status_name"] == "converged", info
+    assert abs(info["objective"] - ref) <= 1e-6 * max(1.0, abs(ref))
+    assert info["rp"] <= 1e-6 and info["rd"] <= 1e-6 and info["gap"] <= 1e-8
+    assert abs(info["iterations"] - int(e["iterations"])) <= 2
+    assert not O.check_optimality(*O.as_float64_problem(A, b, c), x, y, s, 1e-8, 1e-8, 1e-8)
+
+
+def test_auto_rule_and_dense_fallback(golden_dir):
+    A, b, c = _lp(golden_dir, "STOCFOR3")
+    with ipm.IpmSolver(A, b, c) as sv:                       # 16675 rows, 2.1e5 factor entries: sparse
+        assert sv.factor == "sparse" and sv.factor_info()["height"] <= 24 and sv.order_info["nnz_factor"] < 3e5
+        sv.init_state(1.0)
+        st = sv.solve(tol=1e-8, max_iter=300)
+        hist = sv.history()
+    ref = float(np.load(os.path.join(golden_dir, "e2e_STOCFOR3.npz"))["objective"])
+    assert st["status"] == 1 and abs(st["objective"] - ref) <= 1e-6 * abs(ref)
+    assert len(hist) == st["iterations"] and st["solve_ms"] / st["iterations"] < 4.0      # (the dense-tile path: 14 ms)
+    A, b, c = _lp(golden_dir, "BNL2")
+    with ipm.IpmSolver(A, b, c) as sv:                       # fronts of 300 rows: the matrix cores win
+        assert sv.factor == "dense" and sv.factor_info() is None
+    A, b, c = _lp(golden_dir, "QAP8")
+    with ipm.IpmSolver(A, b, c, factor="dense") as sv:
+        assert sv.factor == "dense"
+
+
+def test_solve_linear_on_a_sparse_factor_handle(golden_dir):
+    """The linear-solve seam takes a caller's dense SPD matrix: it must not touch the handle's sparse factor."""
+    A, b, c = _lp(golden_dir, "SC205")
+    m = A.shape[0]
+    rng = np.random.default_rng(2)
+    M = rng.standard_normal((m, m))
+    Bd = M @ M.T + m * np.eye(m)
+    rhs = rng.standard_normal(m)
+    with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
+        z0 = sv.normal_solve(rhs)
+        zl, nfix = sv.solve_linear(Bd, rhs)
+        z1 = sv.normal_solve(rhs)
+    assert nfix == 0 and rel(zl.ravel(), np.linalg.solve(Bd, rhs)) < 1e-10
+    assert np.array_equal(z0, z1)

@@ -1,0 +1,140 @@
+"""CPU tests of the sparse-factor front end: ipm_order_rows (host-only C ABI) and the C++ oracle of the
+multifrontal scheme over the same symbolic structures (oracle/sparse_chol_oracle.cpp), against dense LAPACK / SuperLU.
+The reference gets this service from scipy's spsolve (SuperLU + COLAMD, main.py:180)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+from interiorpointmethod_amd import _lib
+from interiorpointmethod_amd import solver as S
+from interiorpointmethod_amd.matio import load_npz_problem
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _lp(name):
+    A, b, c, cTlb, valid = load_npz_problem(os.path.join(G, "netlib", name + ".npz"))
+    return sp.csc_matrix(A, dtype=np.float64), b, c
+
+
+@pytest.fixture(scope="module")
+def oracle(built_lib):
+    from oracle import sparse_chol
+    sparse_chol.load()
+    return sparse_chol
+
+
+def _nnz_chol(P, perm):
+    """Entries of the Cholesky factor of the pattern P in the given order (symbolic, by child merging)."""
+    Pp = sp.csc_matrix(P[perm][:, perm])
+    m = Pp.shape[0]
+    struct, kids, total = [None] * m, [[] for _ in range(m)], 0
+    low = sp.tril(Pp, -1).tocsc()
+    for k in range(m):
+        s = set(low.indices[low.indptr[k]:low.indptr[k + 1]].tolist())
+        for ch in kids[k]:
+            s |= struct[ch]
+            struct[ch] = None
+        s.discard(k)
+        struct[k] = s
+        total += len(s) + 1
+        if s:
+            kids[min(s)].append(k)
+    return total
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC205", "BANDM", "SCTAP1", "SHELL", "25FV47"])
+def test_order_rows_is_a_permutation_with_the_fill_it_reports(built_lib, name):
+    A, b, c = _lp(name)
+    perm, info = S.sparse_factor_order(A)
+    m = A.shape[0]
+    assert sorted(perm.tolist()) == list(range(m))
+    Ab = A.copy()
+    Ab.data[:] = 1.0
+    P = sp.csr_matrix(Ab @ Ab.T)
+    P.data[:] = 1.0
+    assert info["nnz_pattern"] == sp.tril(P, -1).nnz
+    assert info["nnz_factor"] == _nnz_chol(P, perm)             # the reported fill is the fill of the returned order
+    assert info["nnz_factor"] <= _nnz_chol(P, np.arange(m))     # ... and no worse than the natural order
+    # same league as SuperLU's minimum-degree order on A A^T (the reference's spsolve uses COLAMD)
+    from scipy.sparse.linalg import splu
+    M = (P + sp.eye(m) * (m + 1.0)).tocsc()
+    lu = splu(M, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    assert info["nnz_factor"] <= 1.25 * lu.L.nnz
+    perm2, info2 = S.sparse_factor_order(A)
+    assert np.array_equal(perm, perm2) and info == info2          # a function of the pattern only
+
+
+def test_order_rows_argument_checks(built_lib):
+    lib = _lib.load()
+    i32 = C.POINTER(C.c_int32)
+    cp = np.array([0, 2, 3], dtype=np.int32)
+    ri = np.array([0, 5, 1], dtype=np.int32)                       # row 5 out of range for m = 3
+    perm = np.zeros(3, dtype=np.int32)
+    rc = lib.ipm_order_rows(3, 2, cp.ctypes.data_as(i32), ri.ctypes.data_as(i32), perm.ctypes.data_as(i32), None)
+    assert rc == -1 and b"out of range" in lib.ipm_last_error(None)
+    ri[1] = 2
+    rc = lib.ipm_order_rows(3, 2, cp.ctypes.data_as(i32), ri.ctypes.data_as(i32), perm.ctypes.data_as(i32), None)
+    assert rc == 0 and sorted(perm.tolist()) == [0, 1, 2]
+
+
+def test_order_rows_gives_up_on_a_dense_normal_matrix(built_lib):
+    A, b, c = _lp("QAP8")                                          # A A^T fills to ~dense: the dense-tile path's business
+    rng = np.random.default_rng(0)
+    D = sp.csc_matrix(rng.standard_normal((2500, 40)))             # 2500 x 2500 dense pattern: over the ordering budget
+    perm, info = S.sparse_factor_order(D)
+    assert perm is None and info is None
+    assert not S.prefer_sparse_factor(912, S.sparse_factor_order(A)[1], 8)
+
+
+@pytest.mark.parametrize("name,wcap,lds", [("AFIRO", 32, 7680), ("SC205", 32, 7680), ("BANDM", 32, 7680), ("BANDM", 4, 64),
+                                           ("SHARE2B", 3, 40), ("CZPROB", 32, 7680), ("SCTAP1", 8, 256)])
+def test_multifrontal_oracle_against_lapack(oracle, name, wcap, lds):
+    """L L^T = (A D A^T)(perm, perm) and B z = rhs, for the GPU's panel limits and for tiny ones that force panel splits."""
+    A, b, c = _lp(name)
+    rng = np.random.default_rng(3)
+    d = rng.uniform(0.5, 2.0, A.shape[1])
+    rhs = rng.standard_normal(A.shape[0])
+    out = oracle.factor_solve(A, d, rhs, wcap=wcap, lds=lds)
+    B = (A @ sp.diags(d) @ A.T).toarray()
+    Bp = B[np.ix_(out["perm"], out["perm"])]
+    assert out["fixed"] == 0
+    assert np.abs(out["L"] @ out["L"].T - Bp).max() <= 1e-13 * np.abs(Bp).max()
+    Lref = sla.cholesky(Bp, lower=True)
+    assert np.abs(out["L"] - Lref).max() <= 1e-9 * np.abs(Lref).max()
+    zref = np.linalg.solve(B, rhs)
+    assert np.linalg.norm(out["z"] - zref) <= 1e-9 * np.linalg.norm(zref)
+    assert out["stats"]["max_children"] <= 12                      # fan-in nodes bound the children of a panel
+
+
+def test_multifrontal_oracle_fan_in_nodes_and_guard(oracle):
+    A, b, c = _lp("CZPROB")                                        # a star: hundreds of leaves under one panel
+    out = oracle.factor_solve(A, np.ones(A.shape[1]), np.ones(A.shape[0]), want_factor=False)
+    assert out["stats"]["fan_in_nodes"] > 50 and out["stats"]["height"] <= 12
+    # dependent rows: the guard replaces the pivot (LIPSOL rule, oracle/ipm_oracle.py::guarded_cholesky) and z stays finite
+    A2 = sp.vstack([A[:40], A[:3]]).tocsc()
+    out2 = oracle.factor_solve(A2, np.ones(A2.shape[1]), np.ones(A2.shape[0]), eps=1e-12)
+    assert out2["fixed"] == 3 and np.all(np.isfinite(out2["z"]))
+    from oracle import ipm_oracle as O
+    B2 = (A2 @ A2.T).toarray()
+    Lg, nfix = O.guarded_cholesky(B2[np.ix_(out2["perm"], out2["perm"])], eps=1e-12)
+    assert nfix == 3
+    good = np.abs(np.diag(Lg)) < 1e30
+    assert good.sum() == 40 and np.allclose(np.diag(out2["L"])[good], np.diag(Lg)[good], rtol=1e-9)
+    assert np.all(np.diag(out2["L"])[~good] == 1e32)
+
+
+def test_factor_auto_rule_on_the_netlib_suite(built_lib):
+    """Which LPs factor="auto" sends to the sparse path: the genuinely sparse large ones, not the dense-fill ones."""
+    picks = {}
+    for name in ("STOCFOR3", "SIERRA", "STOCFOR2", "CZPROB", "BNL2", "D2Q06C", "GREENBEA", "25FV47", "GROW22", "PILOT"):
+        A, b, c = _lp(name)
+        m = A.shape[0]
+        perm, info = S.sparse_factor_order(A) if S._worth_ordering(A) else (None, None)
+        picks[name] = S.prefer_sparse_factor(m, info, (m + 127) // 128)
+    assert picks == dict(STOCFOR3=True, SIERRA=True, STOCFOR2=True, CZPROB=True, BNL2=False, D2Q06C=False, GREENBEA=False,
+                         **{"25FV47": False}, GROW22=False, PILOT=False)

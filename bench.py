@@ -151,6 +151,9 @@ PARITY_SET = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "
               "STOCFOR1", "STOCFOR2", "STOCFOR3", "TRUSS", "WOODW"]
 
 
+PATHS = {}          # LP name -> "sparse" | "dense": the factorization path IpmSolver's rule picks (filled by load_netlib)
+
+
 def load_netlib(which, max_m=1 << 30):
     """(names, problems, algorithmic flops per iteration) of the committed Netlib fixtures.  which: "all" (73 valid
     benchmarks/ files), "parity" (the 26 the reference converges on), "general" (benchmarks_full through the
@@ -159,16 +162,18 @@ def load_netlib(which, max_m=1 << 30):
     import numpy as np
     from scipy import sparse
     from interiorpointmethod_amd.matio import load_npz_problem
-    from interiorpointmethod_amd.solver import factor_flops
+    from interiorpointmethod_amd.solver import path_flops
     names, probs, flops = [], [], []
 
     def add(nm, A, b, c):
-        # flops of one iteration as the device runs it: sparse contraction sum_j nnz_j^2, the blocked Cholesky inside
-        # the tile envelope (m^3/3 when there is none), 4 m^2 for the four triangular sweeps, 12 nnz for the six SpMVs
+        # flops of one iteration as the device runs it: sparse contraction sum_j nnz_j^2; the Cholesky -- multifrontal
+        # sparse factor: sum over columns of count^2; blocked dense factor: inside the tile envelope, m^3/3 when there is
+        # none --; the four triangular sweeps (4 nnz(L) or 4 m^2); 12 nnz for the six SpMVs
         A = sparse.csc_matrix(A)
         names.append(nm); probs.append((A, b, c))
-        m = A.shape[0]
-        flops.append(float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2)) + factor_flops(A) + 4.0 * m * m + 12.0 * A.nnz)
+        path, f_chol, f_sweeps = path_flops(A)
+        PATHS[nm] = path
+        flops.append(float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2)) + f_chol + f_sweeps + 12.0 * A.nnz)
 
     if which == "general":
         from interiorpointmethod_amd import general_form as G
@@ -211,9 +216,11 @@ def netlib_roofline(names, probs, flops, rec, elapsed, world):
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS * max(world, 1), "unit": "TFLOP/s",
             "frac": ach / (PEAK_FP64_MFMA_TFLOPS * max(world, 1)), "traffic": None,
             "flops_total": total, "iterations_total": int(its.sum()),
-            "note": "sum over LPs of iterations x (sum_j nnz_j^2 + Cholesky flops [m^3/3, or inside the tile envelope where "
-                    "the factorization skips structural zeros] + 4 m^2 + 12 nnz) / wall / (78.6 TFLOP/s x GPUs); the suite is "
-                    "bound by the per-iteration launch chain, not by flops",
+            "sparse_factor_lps": sorted(nm for nm in names if PATHS.get(nm) == "sparse"),
+            "note": "sum over LPs of iterations x (sum_j nnz_j^2 + Cholesky flops [sparse multifrontal factor: sum over columns of "
+                    "count^2; dense-tile factor: m^3/3, or inside the tile envelope] + sweeps [4 nnz(L) or 4 m^2] + 12 nnz) / "
+                    "wall / (78.6 TFLOP/s x GPUs); the suite is bound by dependent steps (pivot chain / elimination-tree "
+                    "levels), not by flops",
             "latency_floor": {"model": "iterations x (0.1 ms + 0.11 ms per 128-row block) summed over the LPs, one LP at a "
                                        "time on one GPU (round-1 measurement, batch.predicted_cost)",
                               "chain_seconds_one_gpu": chain_s, "measured_wall_seconds": elapsed,

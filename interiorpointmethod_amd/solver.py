@@ -99,9 +99,13 @@ def prefer_sparse_factor(m, info, dense_blocks):
     on the matrix cores.  Sparse wins where the factor is genuinely sparse."""
     if info is None or m < SPARSE_FACTOR_MIN_ROWS:
         return False
-    t_sparse = 0.45 + info["flops"] / 3.0e6 + 0.004 * info["height"]     # ms per iteration (GROW22: 1320 rows, tree height 900)
+    # ms per iteration; a tree taller than ~200 columns is a pivot chain of its own (GROW22: 1320 rows, height 900)
+    t_sparse = 0.45 + info["flops"] / 3.0e6 + 0.004 * max(0, info["height"] - 200)
     t_dense = 0.1 + 0.08 * dense_blocks
-    return t_sparse < t_dense
+    # The model misses tree shape (measured sparse / dense: SCFXM3 0.79 / 0.63, NESM 2.87 / 1.77, GROW15 2.66 / 0.71 ms against
+    # predictions of 0.55, 1.25, 0.93): only a predicted gain of 1.5x switches paths.  Every measured loser stays dense;
+    # of the measured winners only SCTAP2 (0.66 / 0.84) and GFRD-PNC (0.36 / 0.65) are left behind.
+    return 1.5 * t_sparse < t_dense
 
 
 def _worth_ordering(A):
@@ -109,6 +113,20 @@ def _worth_ordering(A):
     c (c - 1) / 2).  Beyond a few million the factor is close to dense and the ordering would only burn host time."""
     c = np.diff(A.indptr).astype(np.float64)
     return float(np.sum(c * (c - 1.0) / 2.0)) <= 4.0e6
+
+
+def path_flops(A, factor=None):
+    """(path, Cholesky flops, flops of the four triangular sweeps) of one iteration AS THE DEVICE RUNS IT for this A under
+    IpmSolver's factor rule: the sparse factor costs sum over columns of (entries of the column)^2 and 4 nnz(L); the
+    dense-tile path factor_flops(A) and 4 m^2.  bench.py's roofline denominator for the Netlib runs."""
+    m = A.shape[0]
+    factor = factor or os.environ.get("IPM_FACTOR", "auto")
+    if _sp is not None and _sp.issparse(A) and factor != "dense" and \
+            (factor == "sparse" or (m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(_sp.csc_matrix(A)))):
+        perm, info = sparse_factor_order(A)
+        if perm is not None and (factor == "sparse" or prefer_sparse_factor(m, info, (m + 127) // 128)):
+            return "sparse", float(info["flops"]), 4.0 * info["nnz_factor"]
+    return "dense", factor_flops(A), 4.0 * m * m
 
 
 def factor_flops(A, nb=128):

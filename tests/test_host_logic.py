@@ -110,9 +110,10 @@ def test_results_table_layout_matches_reference_log(tmp_path):
 
 
 def test_bench_netlib_helpers():
-    """bench.py's Netlib leg: the parity set loads (26 LPs), the flop model uses the tile envelope where the device
-    does (STOCFOR3's factor is ~12 % of m^3/3), the roofline record has the contract keys, and a PMC file collected
-    for another kernel source is refused."""
+    """bench.py's Netlib leg: the parity set loads (26 LPs), the flop model follows the factorization path the solver
+    takes (STOCFOR3: the sparse multifrontal factor, a few 1e6 flop per iteration; under IPM_FACTOR=dense the tile
+    envelope, ~12 % of m^3/3), the roofline record has the contract keys, and a PMC file collected for another kernel
+    source is refused."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import importlib.util
@@ -123,7 +124,11 @@ def test_bench_netlib_helpers():
     assert len(names) == 26 and names == sorted(B.PARITY_SET)
     i = names.index("STOCFOR3")
     m = probs[i][0].shape[0]
-    assert 0.05 * m ** 3 / 3 < flops[i] < 0.25 * m ** 3 / 3
+    assert B.PATHS["STOCFOR3"] == "sparse" and B.PATHS["MAROS-R7"] == "dense" and B.PATHS["AFIRO"] == "dense"
+    assert 2e6 < flops[i] < 2e7
+    from interiorpointmethod_amd.solver import path_flops
+    path, f_chol, f_sweeps = path_flops(probs[i][0], factor="dense")
+    assert path == "dense" and 0.05 * m ** 3 / 3 < f_chol < 0.25 * m ** 3 / 3 and f_sweeps == 4.0 * m * m
     j = names.index("AFIRO")
     assert flops[j] > 27 ** 3 / 3
     rec = np.zeros((26, batch.NF)); rec[:, 0] = np.arange(26); rec[:, 1] = 1; rec[:, 2] = 30; rec[:, 7] = 0.01

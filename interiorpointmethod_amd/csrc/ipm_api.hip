@@ -563,7 +563,9 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     }
     // (every task costs one draw from ONE atomic counter, every workgroup one more: a few hundred of each keep that queue
     //  off the critical path -- measured: 2048 workgroups drawing 3000 tasks spend 0.2 ms per sweep on the counter alone)
-    const int threads = (getenv("IPM_SP_THREADS") ? atoi(getenv("IPM_SP_THREADS")) : (S.rmax <= 64 ? 64 : SPC_THREADS)) == 64 ? 64 : SPC_THREADS;
+    // one-wave workgroups (four times the panels in flight) are an option, not the default: measured 35 % SLOWER at STOCFOR3
+    // (fronts of <= 56 rows): a panel is instruction-latency bound and 256 threads share its loops
+    const int threads = (getenv("IPM_SP_THREADS") && atoi(getenv("IPM_SP_THREADS")) == 64) ? 64 : SPC_THREADS;
     double div = threads == 64 ? 3072.0 : 1536.0;
     if (const char* e = getenv("IPM_SP_TASK_DIV")) div = std::max(1.0, atof(e));
     const double T = std::max(8.0, total / div);
@@ -680,6 +682,7 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     if ((rc = sp_alloc_zero(h, (size_t)nslot, &F.L))) return rc;
     if ((rc = sp_alloc_zero(h, (size_t)S.uptr[nsn], &F.U))) return rc;
     if ((rc = sp_alloc_zero(h, S.rows.size(), &F.uvec))) return rc;
+    if ((rc = sp_alloc_zero(h, (size_t)m, &F.dinv))) return rc;
     if ((rc = sp_alloc_zero(h, (size_t)3 * nsn, &F.flag))) return rc;
     if ((rc = sp_alloc_zero(h, (size_t)8, &F.ctr))) return rc;
     F.timeout = h->d_flags + 2 * (size_t)h->nblk;
@@ -1035,8 +1038,8 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
     if (sp_on(h) && !dense_image) {
         // the entries of B go straight into the panels of the sparse factor (one thread per slot, fixed term order)
         hipLaunchKernelGGL(sp_form_kernel, dim3((unsigned)((h->sp_nslot + 255) / 256)), dim3(256), 0, h->stream, h->sp_fptr, h->sp_fcol,
-                           h->sp_fcoef, h->sp_nslot, d, h->spF.L, &h->sc->done);
-        hipLaunchKernelGGL(sp_maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->spF.L, h->sp_diagpos, (int)h->m, &h->sc->maxdiag,
+                           h->sp_fcoef, h->sp_nslot, d, h->spF.L, &h->sc->maxdiag, &h->sc->done);
+        hipLaunchKernelGGL(sp_maxdiag_kernel, dim3((unsigned)((h->m + 255) / 256)), dim3(256), 0, h->stream, h->spF.L, h->sp_diagpos, (int)h->m, &h->sc->maxdiag,
                            &h->sc->done);
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;

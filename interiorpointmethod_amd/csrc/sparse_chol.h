@@ -64,6 +64,7 @@ struct SpFactor {
     double* L;                           // panel values
     double* U;                           // update matrices (uptr)
     double* uvec;                        // forward sweep: update vector of J at uvec[rowptr[J] + w ..)
+    double* dinv;                        // [m] 1 / L_cc, written by the factorization
     unsigned* flag;                      // [3 nsn]: chol, forward, backward (epoch of the last completed launch)
     unsigned* ctr;                       // [6]: {next task, exited workgroups} x 3
     unsigned* timeout;
@@ -124,9 +125,10 @@ __device__ __forceinline__ void sp_leave(unsigned* ctr) {
 // slot; slot e sums fcoef[t] d[fcol[t]] over its product list (columns ascending: fixed order).  fcoef = a_ij a_kj.
 __global__ __launch_bounds__(256) void sp_form_kernel(const int* __restrict__ fptr, const int* __restrict__ fcol,
                                                       const double* __restrict__ fcoef, long long nslot,
-                                                      const double* __restrict__ d, double* L, const int* done) {
+                                                      const double* __restrict__ d, double* L, double* maxdiag, const int* done) {
     if (done && *done) return;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e == 0) *maxdiag = 0.0;                             // sp_maxdiag_kernel (next in the stream) takes an atomic max into it
     if (e >= nslot) return;
     const int t0 = fptr[e], t1 = fptr[e + 1];
     double acc = 0.0;
@@ -134,19 +136,23 @@ __global__ __launch_bounds__(256) void sp_form_kernel(const int* __restrict__ fp
     L[e] = acc;
 }
 
+// max diag(B) for the pivot-guard threshold: grid of 256-thread blocks, block maxima merged with an integer atomic max on the bit
+// pattern (non-negative doubles order like their bits; max is order independent, so this atomic keeps results reproducible).
+// *out was set to 0 by sp_form_kernel; negative or NaN diagonals never win, as in the dense path's maxdiag_kernel.
 __global__ __launch_bounds__(256) void sp_maxdiag_kernel(const double* L, const long long* __restrict__ diagpos, int m, double* out,
                                                          const int* done) {
     if (done && *done) return;
     __shared__ double red[256];
-    double mx = -1.7976931348623157e308;
-    for (int i = threadIdx.x; i < m; i += 256) { const double v = L[diagpos[i]]; mx = (v > mx) ? v : mx; }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double mx = 0.0;
+    if (i < m) { const double v = L[diagpos[i]]; mx = (v > 0.0) ? v : 0.0; }
     red[threadIdx.x] = mx;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = red[0];
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(red[0]));
 }
 
 // ------------------------------------------------------------------------------------------------------------ factorization
@@ -243,8 +249,10 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                     double pv = P[c * ldp + c];
                     const bool bad = !(pv > thresh);
                     if (bad) pv = big;
-                    if (tid == 0) { rs[c] = 1.0 / sqrt(pv); if (bad) { ++nfix; P[c * ldp + c] = big; } }
-                    const double ipv = 1.0 / pv;
+                    double root, rinv;
+                    sqrt_rsqrt(pv, root, rinv);                    // v_rsq_f64 + one Halley step (potrf_f64.h): the pivot chain is serial
+                    if (tid == 0) { rs[c] = rinv; if (bad) { ++nfix; P[c * ldp + c] = big; } }
+                    const double ipv = rinv * rinv;
                     const int b = c + 1 + bl;
                     if (b < w) {
                         const double fb = P[b * ldp + c] * ipv;
@@ -293,6 +301,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                 }
             }
             for (int idx = tid; idx < r * w; idx += NT) { const int a = idx / w, b = idx - a * w; Lp[idx] = P[a * ldp + b]; }
+            if (tid < w) f.dinv[rc.c0 + tid] = rs[tid];             // 1 / L_cc for the substitutions (a multiply per step instead of a divide)
             if (rc.publish) sp_publish(flag + rc.J, epoch);
         }
     }
@@ -330,19 +339,42 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
             double* uv = f.uvec + rc.rowptr;
             for (int a = tid; a < r; a += NT) fv[a] = a < w ? rhs[rc.c0 + a] : 0.0;
             for (int idx = tid; idx < w * w; idx += NT) D[idx] = Lp[idx];
-            __syncthreads();
-            for (int t = 0; t < nchild; ++t) {
-                const int pc = rc.ch[t].pc;
-                const double* uc = f.uvec + rc.ch[t].relptr;
-                const int* rel = f.crel + rc.ch[t].relptr;
-                for (int i = tid; i < pc; i += NT) fv[rel[i]] += uc[i];
-                __syncthreads();
+            // children's update vectors: every load is issued before the first add (a child shorter than the workgroup gives each
+            // thread at most one entry), the adds then go child by child with LDS-only barriers -- one memory latency for the
+            // whole extend-add instead of one per child
+            double cu[SPC_MAXCH];
+            int cr[SPC_MAXCH];
+            bool all_short = true;
+#pragma unroll
+            for (int t = 0; t < SPC_MAXCH; ++t) {
+                cr[t] = -1; cu[t] = 0.0;
+                if (t < nchild) {
+                    const int pc = rc.ch[t].pc;
+                    all_short = all_short && pc <= NT;
+                    if (tid < pc) { cu[t] = f.uvec[rc.ch[t].relptr + tid]; cr[t] = f.crel[rc.ch[t].relptr + tid]; }
+                }
             }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < SPC_MAXCH; ++t) {
+                if (t < nchild) {
+                    if (cr[t] >= 0) fv[cr[t]] += cu[t];
+                    const int pc = rc.ch[t].pc;
+                    if (pc > NT) {
+                        const double* uc = f.uvec + rc.ch[t].relptr;
+                        const int* rel = f.crel + rc.ch[t].relptr;
+                        for (int i = NT + tid; i < pc; i += NT) fv[rel[i]] += uc[i];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+            }
+            (void)all_short;
             if (tid < 64 && w > 0) {                          // w x w lower triangular solve in the registers of wave 0 (w <= 32)
                 const int ln = tid < w ? tid : 0;
                 double fa = fv[ln];
+                const double di = f.dinv[rc.c0 + ln];
                 for (int c = 0; c < w; ++c) {
-                    const double zc = readlane_f64(fa, c) / D[c * w + c];
+                    const double zc = readlane_f64(fa, c) * readlane_f64(di, c);
                     if (tid == c) fa = zc;
                     else if (tid > c && tid < w) fa -= D[tid * w + c] * zc;
                 }
@@ -411,8 +443,9 @@ __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, 
                         for (int sl = 0; sl < NSL; ++sl) s += part[sl * SPC_WCAP + tid];
                         ga = z[rc.c0 + tid] - s;
                     }
+                    const double di = f.dinv[rc.c0 + (tid < w ? tid : 0)];
                     for (int c = w - 1; c >= 0; --c) {
-                        const double xc = readlane_f64(ga, c) / D[c * w + c];
+                        const double xc = readlane_f64(ga, c) * readlane_f64(di, c);
                         if (tid == c) ga = xc;
                         else if (tid < c) ga -= D[c * w + tid] * xc;
                     }

@@ -103,6 +103,35 @@ __device__ __forceinline__ void sp_publish(unsigned* flag, unsigned epoch) {
     }
 }
 
+// Hand-off WITHOUT fences (template parameter SC1; opt-in, IPM_SP_SC1=1): every byte another workgroup will read is stored write-through
+// (agent-scope relaxed atomic store = global_store ... sc1) and every load of such bytes is an sc1 load (bypasses this CU's L1);
+// producer: every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 stores the flag sc1; consumer: wave 0
+// polls the flag sc1, workgroup barrier, sc1 loads.  (MI355X_MICROARCH.md, inter-workgroup visibility, "valid forms": conditions
+// (1)-(3).)  Measured at STOCFOR3: a level of the tree costs ~10 us with the fence pair (release 1.7-6.5 us + acquire 1.7 us
+// + poll) against 1.4-3.9 us for the panel itself; without the fences a sweep is 8-12 % faster.  SC1 = false (the default)
+// keeps plain accesses and the release / acquire fences.
+template <bool SC1> __device__ __forceinline__ double sp_ld(const double* p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool SC1> __device__ __forceinline__ void sp_st(double* p, double v) {
+    if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool SC1> __device__ __forceinline__ void sp_consume_barrier() {
+    if constexpr (SC1) { asm volatile("" ::: "memory"); __syncthreads(); }
+    else sp_acquire_barrier();
+}
+template <bool SC1> __device__ __forceinline__ void sp_signal(unsigned* flag, unsigned epoch) {
+    if constexpr (SC1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        sp_publish(flag, epoch);
+    }
+}
+
 // draw the next task (workgroup-uniform); the last workgroup to leave resets the two counters for the next launch
 __device__ __forceinline__ int sp_next_task(unsigned* ctr, int* s_task) {
     __syncthreads();
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(256) void sp_maxdiag_kernel(const double* L, const 
 // workgroup barrier between children -- the work is the children's entries, not (front entries) x (children), and the
 // order of additions is fixed.  Fan-in nodes (w = 0) only do this step.  Everything a panel needs to start (its sizes,
 // offsets and those of its children) sits in one record in task order (SpRec), read with uniform loads.
-template <int NT>
+template <int NT, bool SC1>
 __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch, const double* maxdiag, double eps,
                                                               double big, double shift_rel, int* fixed, int lds) {
     if (f.done && *f.done) return;
@@ -186,7 +215,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
             const int ldp = front ? r : w;
             if (rc.wait_children) {
                 if (tid < nchild && rc.ch[tid].ext) (void)sp_wait(flag + rc.ch[tid].K, epoch, f.timeout);   // (a time-out poisons the results; the host reruns the launch)
-                sp_acquire_barrier();
+                sp_consume_barrier<SC1>();
             } else {
                 __syncthreads();                            // the previous panel of this task is complete (its U is in memory)
             }
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                 }
             } else {
                 for (int idx = tid; idx < r * w; idx += NT) P[idx] = Lp[idx];
-                if (kids) for (int idx = tid; idx < p * p; idx += NT) Up[idx] = 0.0;
+                if (kids) for (int idx = tid; idx < p * p; idx += NT) sp_st<SC1>(Up + idx, 0.0);
             }
             __syncthreads();
             if (shift != 0.0) {
@@ -224,17 +253,17 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                         if (e < pc * pc) {
                             const int i = e / pc, j = e - i * pc;
                             if (j <= i) {
-                                v[k] = Uc[e];
+                                v[k] = sp_ld<SC1>(Uc + e);
                                 const int a = rel[i], b = rel[j];
                                 tg[k] = (front || b < w) ? -(long long)(a * ldp + b) - 2 : (long long)(a - w) * p + (b - w);
                             }
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < SPC_BATCH; ++k) old[k] = tg[k] >= 0 ? Up[tg[k]] : 0.0;
+                    for (int k = 0; k < SPC_BATCH; ++k) old[k] = tg[k] >= 0 ? sp_ld<SC1>(Up + tg[k]) : 0.0;
 #pragma unroll
                     for (int k = 0; k < SPC_BATCH; ++k) {
-                        if (tg[k] >= 0) Up[tg[k]] = old[k] + v[k];
+                        if (tg[k] >= 0) sp_st<SC1>(Up + tg[k], old[k] + v[k]);
                         else if (tg[k] <= -2) P[-(tg[k] + 2)] += v[k];
                     }
                 }
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                     const double* rb = P + (w + j) * r;
                     double dot = 0.0;
                     for (int c = 0; c < w; ++c) dot += ra[c] * rb[c];
-                    Up[idx] = ra[w + j] - dot;
+                    sp_st<SC1>(Up + idx, ra[w + j] - dot);
                 }
             } else if (w > 0) {
                 for (int e0 = tid; e0 < p * p; e0 += SPC_BATCH * NT) {
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                     for (int k = 0; k < SPC_BATCH; ++k) {
                         const int idx = e0 + k * NT;
                         on[k] = idx < p * p && (idx % p) <= (idx / p);
-                        old[k] = (on[k] && kids) ? Up[idx] : 0.0;
+                        old[k] = (on[k] && kids) ? sp_ld<SC1>(Up + idx) : 0.0;
                     }
 #pragma unroll
                     for (int k = 0; k < SPC_BATCH; ++k) {
@@ -296,13 +325,13 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                         const double* rb = P + (w + j) * w;
                         double dot = 0.0;
                         for (int c = 0; c < w; ++c) dot += ra[c] * rb[c];
-                        Up[idx] = old[k] - dot;
+                        sp_st<SC1>(Up + idx, old[k] - dot);
                     }
                 }
             }
             for (int idx = tid; idx < r * w; idx += NT) { const int a = idx / w, b = idx - a * w; Lp[idx] = P[a * ldp + b]; }
             if (tid < w) f.dinv[rc.c0 + tid] = rs[tid];             // 1 / L_cc for the substitutions (a multiply per step instead of a divide)
-            if (rc.publish) sp_publish(flag + rc.J, epoch);
+            if (rc.publish) sp_signal<SC1>(flag + rc.J, epoch);
         }
     }
     if (tid == 0 && nfix) atomicAdd(fixed, nfix);
@@ -312,7 +341,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
 // ------------------------------------------------------------------------------------------------------------ L z = rhs
 // z may alias rhs.  Panel J: f = rhs(J's columns) + children's update vectors (child-major, as the factorization);
 // z_J = L_JJ^{-1} f_top; the rows below get f_below - L_21 z_J, handed to the parent.  Dynamic LDS: rmax + 1024 doubles.
-template <int NT>
+template <int NT, bool SC1>
 __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, const double* rhs, double* z, int rmax) {
     if (f.done && *f.done) return;
     extern __shared__ __attribute__((aligned(16))) double fv[];
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
             const int r = rc.r, w = rc.w, nchild = rc.nchild;
             if (rc.wait_children) {
                 if (tid < nchild && rc.ch[tid].ext) (void)sp_wait(flag + rc.ch[tid].K, epoch, f.timeout);
-                sp_acquire_barrier();
+                sp_consume_barrier<SC1>();
             } else {
                 __syncthreads();
             }
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
                 if (t < nchild) {
                     const int pc = rc.ch[t].pc;
                     all_short = all_short && pc <= NT;
-                    if (tid < pc) { cu[t] = f.uvec[rc.ch[t].relptr + tid]; cr[t] = f.crel[rc.ch[t].relptr + tid]; }
+                    if (tid < pc) { cu[t] = sp_ld<SC1>(f.uvec + rc.ch[t].relptr + tid); cr[t] = f.crel[rc.ch[t].relptr + tid]; }
                 }
             }
             __syncthreads();
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
                     if (pc > NT) {
                         const double* uc = f.uvec + rc.ch[t].relptr;
                         const int* rel = f.crel + rc.ch[t].relptr;
-                        for (int i = NT + tid; i < pc; i += NT) fv[rel[i]] += uc[i];
+                        for (int i = NT + tid; i < pc; i += NT) fv[rel[i]] += sp_ld<SC1>(uc + i);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
@@ -387,10 +416,10 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
                     const double* row = Lp + (long long)a * w;
                     double dot = 0.0;
                     for (int c = 0; c < w; ++c) dot += row[c] * fv[c];
-                    uv[a] = fv[a] - dot;
+                    sp_st<SC1>(uv + a, fv[a] - dot);
                 }
             }
-            if (rc.publish) sp_publish(flag + rc.J, epoch);
+            if (rc.publish) sp_signal<SC1>(flag + rc.J, epoch);
         }
     }
     sp_leave(ctr);
@@ -399,7 +428,7 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
 // ------------------------------------------------------------------------------------------------------------ L^T x = z
 // x may alias z.  Panels in DESCENDING order: x_J = L_JJ^{-T} (z_J - L_21^T x(rows below)); the rows below belong to
 // ancestors, whose x is final once the parent's flag is up.
-template <int NT>
+template <int NT, bool SC1>
 __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, const double* z, double* x) {
     if (f.done && *f.done) return;
     constexpr int NSL = NT / 32;
@@ -420,7 +449,7 @@ __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, 
             const int r = rc.r, w = rc.w, p = r - w;
             if (rc.publish) {                                        // the parent belongs to another task
                 if (tid == 0) (void)sp_wait(flag + rc.parent, epoch, f.timeout);
-                sp_acquire_barrier();
+                sp_consume_barrier<SC1>();
             } else {
                 __syncthreads();
             }
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, 
                 {
                     const int c = tid & (SPC_WCAP - 1), sl = tid >> 5;          // NT threads = 32 columns x NSL slices
                     double acc = 0.0;
-                    if (c < w) for (int i = sl; i < p; i += NSL) acc += Lp[(long long)(w + i) * w + c] * x[rows[w + i]];
+                    if (c < w) for (int i = sl; i < p; i += NSL) acc += Lp[(long long)(w + i) * w + c] * sp_ld<SC1>(x + rows[w + i]);
                     part[sl * SPC_WCAP + c] = acc;
                 }
                 for (int idx = tid; idx < w * w; idx += NT) D[idx] = Lp[idx];
@@ -449,10 +478,10 @@ __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, 
                         if (tid == c) ga = xc;
                         else if (tid < c) ga -= D[c * w + tid] * xc;
                     }
-                    if (tid < w) x[rc.c0 + tid] = ga;
+                    if (tid < w) sp_st<SC1>(x + rc.c0 + tid, ga);
                 }
             }
-            if (rc.wait_children) sp_publish(flag + rc.J, epoch);       // some child belongs to another task: it waits for this x
+            if (rc.wait_children) sp_signal<SC1>(flag + rc.J, epoch);       // some child belongs to another task: it waits for this x
         }
     }
     sp_leave(ctr);

@@ -2,12 +2,15 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-IPM_FACTOR=dense timeout -k 10 300 python bench.py --workload netlib --netlib-set all --no-cpu-baseline > gpurun_out/suite_dense.json 2> gpurun_out/suite_dense.err || { tail -5 gpurun_out/suite_dense.err; exit 1; }
-timeout -k 10 300 python bench.py --workload netlib --netlib-set all --no-cpu-baseline > gpurun_out/suite_auto.json 2> gpurun_out/suite_auto.err || { tail -5 gpurun_out/suite_auto.err; exit 1; }
-timeout -k 10 300 python bench.py --workload netlib --netlib-set all --no-cpu-baseline > gpurun_out/suite_auto2.json 2> gpurun_out/suite_auto2.err || { tail -5 gpurun_out/suite_auto2.err; exit 1; }
+for g in 64 256 100000; do
+  IPM_SP_GRID=$g timeout -k 10 400 python bench.py --workload netlib --netlib-set all --no-cpu-baseline > gpurun_out/all_g$g.json 2> gpurun_out/all_g$g.err || { tail -5 gpurun_out/all_g$g.err; exit 1; }
+  IPM_SP_GRID=$g timeout -k 10 400 python bench.py --workload netlib --netlib-set general --start-point mehrotra --no-cpu-baseline > gpurun_out/genm_g$g.json 2> gpurun_out/genm_g$g.err || { tail -5 gpurun_out/genm_g$g.err; exit 1; }
+done
 python - <<'PY'
 import json
-for f in ("suite_dense","suite_auto","suite_auto2"):
-    d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1])
-    print(f, "value=%.3f LPs/s wall=%.3f"%(d["value"], d["wall_seconds"]), d["summary"])
+for g in (64,256,100000):
+  for f in ("all","genm"):
+    d=json.loads(open("gpurun_out/%s_g%d.json"%(f,g)).read().strip().splitlines()[-1])
+    p=d["per_lp"]
+    print(f, g, "value=%.3f LPs/s wall=%.3f conv=%d its=%d"%(d["value"], d["wall_seconds"], d["summary"]["converged"], d["summary"]["total_iterations"]), {k:p[k]["s"] for k in ("STOCFOR3","STOCFOR2","CZPROB","SCTAP3","SIERRA","80BAU3B","SHELL")})
 PY

@@ -1,13 +1,19 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-R=$PWD
-mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_sparse_factor.py "tests/test_gpu_parity.py::test_netlib_suite_batched_config4" "tests/test_gpu_parity.py::test_netlib_parity" -m gpu -x -q > gpurun_out/pytest_spf.log 2>&1 || { tail -30 gpurun_out/pytest_spf.log; exit 1; }
-tail -2 gpurun_out/pytest_spf.log
-timeout -k 10 600 python tools/sparse_factor_check.py --no-dense STOCFOR3 SIERRA STOCFOR2 CZPROB SCTAP3 SHELL 80BAU3B GANGES SCFXM3 NESM GREENBEA > gpurun_out/spf_check.log 2>&1
-grep -v amdgpu.ids gpurun_out/spf_check.log | awk '{print $1, $2, $3, $4, $(NF-4), $(NF-3), $(NF-2), $(NF-1)}'
-cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/spf_prof_STOCFOR3
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/spf_prof_STOCFOR3 -o p -- python3 $R/tools/sparse_factor_check.py --no-dense STOCFOR3 > $R/gpurun_out/spf_prof_STOCFOR3.log 2>&1
-cd $R && python tools/prof_db_stats.py gpurun_out/spf_prof_STOCFOR3 4; rm -f gpurun_out/spf_prof_STOCFOR3/*.db
+export IPM_SP_XCD_REPORT=1
+for x in 0 1; do
+IPM_SP_XCD=$x IPM_SP_XCD_PROTO=0 python - <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, scipy.sparse as sp
+from interiorpointmethod_amd.matio import load_npz_problem
+from interiorpointmethod_amd.solver import IpmSolver
+A,b,c,_,v=load_npz_problem("tests/golden/netlib/STOCFOR2.npz")
+for k in range(3):
+    with IpmSolver(sp.csc_matrix(A),b,c,factor="sparse") as sv:
+        z=sv.normal_solve(np.ones(A.shape[0]))
+        fi=sv.factor_info()
+        print("IPM_SP_XCD=%s handle %d: xcc mask = %s grid-ish tasks=%d" % (os.environ["IPM_SP_XCD"], k, bin(fi["serial_launches"]>>32), fi["tasks"]))
+PY
+done

@@ -218,7 +218,10 @@ class IpmSolver:
         opts = _lib.Options()
         lib.ipm_default_options(C.byref(opts))
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big
-        opts.check_every = int(check_every)
+        ce = int(check_every)
+        if os.environ.get("IPM_CHECK_EVERY"):
+            ce = int(os.environ["IPM_CHECK_EVERY"])
+        opts.check_every = ce
         opts.regularize = float(regularize)
         # concurrent=True: this handle shares the GPU with others (batched mode) -- one stream per handle, no look-ahead, no
         # device polling (include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM).  Without it the library still protects itself (it

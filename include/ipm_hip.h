@@ -196,11 +196,13 @@ int ipm_get_schedule(ipm_handle* h, int32_t out[10]);
 /* Fill-reducing order of the ROWS of an m x n sparse A (CSC, host) for the Cholesky of A D^2 A^T: minimum degree on
  * the pattern of A A^T followed by the elimination-tree postorder.  Pure host code (no device is touched): the
  * reference gets the same service from SuperLU's COLAMD inside spsolve (main.py:180).  perm[new] = old, length m.
- * info (may be NULL): [0] entries of the strict lower triangle of A A^T, [1] entries of the Cholesky factor in this
- * order (diagonal included), [2] multiply-adds of that factorization (sum over columns of count^2), [3] height of the
- * elimination tree in columns.  Returns IPM_OK; IPM_ERR_WORKSPACE when the pattern or the ordering work exceeds the
+ * info (may be NULL, 8 doubles): [0] entries of the strict lower triangle of A A^T, [1] entries of the Cholesky factor in
+ * this order (diagonal included), [2] multiply-adds of that factorization (sum over columns of count^2), [3] height of the
+ * elimination tree in columns; of the panel tree the device would walk (the analysis ipm_set_A_csc runs): [4] its height in
+ * panels, [5] the largest sum of (front rows)^2 along a root-to-leaf path, [6] panels, [7] rows of the widest front
+ * ([4..7] zero when that analysis exceeds its caps).  Returns IPM_OK; IPM_ERR_WORKSPACE when the pattern or the ordering work exceeds the
  * built-in caps (A A^T close to dense: keep the dense path), perm is then the identity. */
-int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[4]);
+int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[8]);
 /* Structure of the sparse factor of a handle created with IPM_FLAG_SPARSE_FACTOR (IPM_ERR_STATE otherwise):
  * out[0] panels, [1] tasks, [2] panel-tree height, [3] widest front (rows), [4] entries of L stored, [5] entries of the
  * update matrices, [6] product-list terms of the formation, [7] launches that fell back to one workgroup after a

@@ -711,10 +711,10 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     return IPM_OK;
 }
 
-extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[4]) {
+extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[8]) {
     if (m <= 0 || n <= 0 || !colptr || !rowind || !perm || m > (1 << 24)) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: bad arguments");
     for (int64_t i = 0; i < m; ++i) perm[i] = (int32_t)i;
-    if (info) info[0] = info[1] = info[2] = info[3] = 0.0;
+    if (info) for (int k = 0; k < 8; ++k) info[k] = 0.0;
     if (colptr[0] != 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: colptr[0] != 0");
     for (int64_t j = 0; j < n; ++j) {
         if (colptr[j + 1] < colptr[j]) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: colptr not monotone");
@@ -725,7 +725,26 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
     sym::OrderInfo oi;
     if (sym::order_rows((int)m, (int)n, colptr, rowind, pv, oi)) return fail(nullptr, IPM_ERR_WORKSPACE, "ipm_order_rows: A A^T is too dense for the sparse factor");
     for (int64_t i = 0; i < m; ++i) perm[i] = pv[(size_t)i];
-    if (info) { info[0] = (double)oi.nnz_pattern; info[1] = (double)oi.nnz_factor; info[2] = oi.flops; info[3] = (double)oi.height; }
+    if (info) {
+        info[0] = (double)oi.nnz_pattern; info[1] = (double)oi.nnz_factor; info[2] = oi.flops; info[3] = (double)oi.height;
+        // the panel tree the device would walk (same analysis as ipm_set_A_csc runs): what a cost model needs
+        std::vector<int> pos((size_t)m), pcp((size_t)n + 1, 0), pri((size_t)colptr[n]);
+        for (int64_t k = 0; k < m; ++k) pos[(size_t)pv[(size_t)k]] = (int)k;
+        for (int64_t j = 0; j < n; ++j) {
+            for (int32_t q = colptr[j]; q < colptr[j + 1]; ++q) pri[(size_t)q] = pos[(size_t)rowind[q]];
+            pcp[(size_t)j + 1] = colptr[j + 1];
+        }
+        sym::Pattern P;
+        sym::Supernodes S;
+        double relax = 1.0;
+        if (const char* e = getenv("IPM_SP_RELAX")) relax = atof(e);
+        if (sym::normal_pattern((int)m, (int)n, pcp.data(), pri.data(), (int64_t)1.5e8, P) &&
+            sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax) == 0) {
+            double area = 0.0; int levels = 0;
+            sym::critical_path(S, area, levels);
+            info[4] = (double)S.height; info[5] = area; info[6] = (double)S.nsn; info[7] = (double)S.rmax;
+        }
+    }
     return IPM_OK;
 }
 

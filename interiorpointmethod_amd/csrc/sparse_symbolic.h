@@ -462,5 +462,20 @@ inline int analyse(const Pattern& P, int wcap, int lds_doubles, Supernodes& S, i
     return 0;
 }
 
+// Critical path of the panel tree for a cost model: the largest, over root-to-leaf paths, of the sum of (rows of the front)^2,
+// and the number of panels on that path.
+inline void critical_path(const Supernodes& S, double& area, int& levels) {
+    std::vector<double> acc((size_t)S.nsn, 0.0);
+    std::vector<int> lev((size_t)S.nsn, 0);
+    area = 0.0; levels = 0;
+    for (int J = 0; J < S.nsn; ++J) {                        // children precede parents
+        const double r = (double)(S.rowptr[(size_t)J + 1] - S.rowptr[J]);
+        acc[J] += r * r; lev[J] += 1;
+        if (acc[J] > area) { area = acc[J]; levels = lev[J]; }
+        const int pj = S.parent[J];
+        if (pj >= 0 && acc[J] > acc[pj]) { acc[pj] = acc[J]; lev[pj] = lev[J]; }
+    }
+}
+
 }  // namespace sym
 }  // namespace ipm

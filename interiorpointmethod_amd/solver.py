@@ -75,7 +75,7 @@ def sparse_factor_order(A):
     A = _sp.csc_matrix(A)
     m, n = A.shape
     perm = np.zeros(m, dtype=np.int32)
-    info = np.zeros(4)
+    info = np.zeros(8)
     ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
     ii = np.ascontiguousarray(A.indices, dtype=np.int32)
     rc = lib.ipm_order_rows(m, n, ip.ctypes.data_as(C.POINTER(C.c_int32)), ii.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -84,28 +84,28 @@ def sparse_factor_order(A):
         return None, None
     _lib.check(None, rc)
     return perm.astype(np.int64), dict(nnz_pattern=int(info[0]), nnz_factor=int(info[1]), flops=float(info[2]),
-                                       height=int(info[3]))
+                                       height=int(info[3]), panel_height=int(info[4]), path_area=float(info[5]),
+                                       panels=int(info[6]), widest_front=int(info[7]))
 
 
 SPARSE_FACTOR_MIN_ROWS = 600          # below five 128-row blocks the dense chain is shorter than one tree sweep set
 
 
 def prefer_sparse_factor(m, info, dense_blocks):
-    """The rule of factor="auto", fitted to measurements on MI355X (tools/sparse_factor_check.py, ms per iteration,
-    sparse / dense): STOCFOR3 1.2 / 14.0, SIERRA 0.65 / 2.2, STOCFOR2 0.51 / 1.47, CZPROB 0.60 / 0.92, SCTAP3 0.59 / 0.92,
-    SHELL 0.49 / 0.67, 80BAU3B 2.6 / 3.35, GANGES 1.03 / 1.11 -- but 25FV47 1.34 / 0.70, GREENBEA 3.0 / 1.7, BNL2 4.4 / 1.6,
-    D2Q06C 6.4 / 1.6, PILOTNOV 3.3 / 0.9: the sparse factor walks the elimination tree five times per iteration with scalar
-    fp64 work proportional to info["flops"]; the dense-tile path walks a chain of m/128 pivot blocks and does its flops
-    on the matrix cores.  Sparse wins where the factor is genuinely sparse."""
-    if info is None or m < SPARSE_FACTOR_MIN_ROWS:
+    """The rule of factor="auto", fitted to measurements on MI355X (tools/sparse_factor_check.py, one LP on the GPU, ms per
+    iteration sparse / dense): STOCFOR3 1.16 / 14.0, SIERRA 0.64 / 2.2, STOCFOR2 0.49 / 1.47, CZPROB 0.60 / 0.92, SCTAP3
+    0.57 / 0.92, SHELL 0.48 / 0.67, GFRD-PNC 0.36 / 0.65, SCTAP2 0.66 / 0.84, 80BAU3B 2.6 / 3.35, GANGES 1.01 / 1.13 -- but
+    25FV47 1.34 / 0.70, NESM 2.85 / 1.77, GREENBEA 3.2 / 1.73, BNL2 4.4 / 1.62, D2Q06C 6.4 / 1.56, PILOTNOV 3.3 / 0.91, GROW15
+    2.66 / 0.71.  The sparse factor walks the panel tree five times per iteration and every level is a hand-off between
+    workgroups: 0.061 ms per level of the panel tree plus 5.6e-6 ms per (front rows)^2 along the critical path (least
+    squares over 23 LPs, worst error 0.3 ms; info["panel_height"], info["path_area"] from ipm_order_rows).  The dense-tile
+    path walks a chain of m/128 pivot blocks at 0.08 ms each and does its flops on the matrix cores.  A predicted gain of
+    10 % switches paths: of the 23 measured LPs only SCFXM3 (0.54 / 0.63, predicted 0.86) is on the slower path."""
+    if info is None or m < SPARSE_FACTOR_MIN_ROWS or info.get("panel_height", 0) <= 0:
         return False
-    # ms per iteration; a tree taller than ~200 columns is a pivot chain of its own (GROW22: 1320 rows, height 900)
-    t_sparse = 0.45 + info["flops"] / 3.0e6 + 0.004 * max(0, info["height"] - 200)
+    t_sparse = max(0.3, -0.13 + 0.061 * info["panel_height"] + 5.56e-6 * info["path_area"])      # ms per iteration
     t_dense = 0.1 + 0.08 * dense_blocks
-    # The model misses tree shape (measured sparse / dense: SCFXM3 0.79 / 0.63, NESM 2.87 / 1.77, GROW15 2.66 / 0.71 ms against
-    # predictions of 0.55, 1.25, 0.93): only a predicted gain of 1.5x switches paths.  Every measured loser stays dense;
-    # of the measured winners only SCTAP2 (0.66 / 0.84) and GFRD-PNC (0.36 / 0.65) are left behind.
-    return 1.5 * t_sparse < t_dense
+    return 1.1 * t_sparse < t_dense
 
 
 def _worth_ordering(A):

@@ -23,3 +23,12 @@ print("dense", d["value"], d["roofline"]["frac"], "netlib parity", d["netlib"]["
 n=json.loads(open("gpurun_out/final_netlib_all.json").read().strip().splitlines()[-1])
 print("netlib all", n["value"], n["wall_seconds"], n["summary"])
 PY
+# larger dense sizes (MFMA-utilisation evidence, BASELINE config 5)
+timeout -k 10 300 python bench.py --m 8192 --n 16384 --steps 10 --warmup 2 --no-netlib --no-cpu-baseline > gpurun_out/final_dense8k.json 2> gpurun_out/final_dense8k.err || { tail -5 gpurun_out/final_dense8k.err; exit 1; }
+timeout -k 10 400 python bench.py --m 16384 --n 32768 --steps 5 --warmup 1 --no-netlib --no-cpu-baseline > gpurun_out/final_dense16k.json 2> gpurun_out/final_dense16k.err || { tail -5 gpurun_out/final_dense16k.err; exit 1; }
+python - <<'PY'
+import json
+for f in ("final_dense8k", "final_dense16k"):
+    d = json.loads(open("gpurun_out/%s.json" % f).read().strip().splitlines()[-1])
+    print(f, d["value"], d["roofline"]["frac"], d.get("whole_iteration", {}).get("frac_of_fp64_mfma_peak"))
+PY

@@ -107,6 +107,9 @@ struct ipm_handle {
     int sp_height = 0, sp_rmax = 0, sp_grid = 1, sp_serial_launches = 0, sp_nvirtual = 0;
     size_t sp_lds_chol = 0, sp_lds_solve = 0;
     int sp_lds_doubles = 16, sp_threads = 256;
+    int sp_level_mode = 0;                // 1 (IPM_SP_MODE=level): one launch per level of the panel tree, no in-kernel hand-offs; 0: one launch per sweep
+    std::vector<int> sp_lvlptr;           // [levels + 1] into the level-ordered records
+    SpRec* sp_rec_level = nullptr;
     bool sp_sc1 = false;                  // IPM_SP_SC1=1: write-through stores + sc1 loads instead of the release / acquire fence pair
     unsigned sp_epoch = 0;
     double shift_rel = 0.0;               // Tikhonov shift in effect (opt.regularize, or 1e-14 switched on by ipm_solve)
@@ -617,6 +620,21 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
             c.ext = taskof[K] != taskof[J] ? 1 : 0;
         }
     }
+    // level-ordered copy of the records (level = 1 + the highest level among the children): LEVEL mode launches one kernel per level
+    std::vector<int> lvl((size_t)nsn, 1), lvlptr;
+    int nlev = 0;
+    for (int J = 0; J < nsn; ++J) { if (S.parent[J] >= 0) lvl[S.parent[J]] = std::max(lvl[S.parent[J]], lvl[J] + 1); nlev = std::max(nlev, lvl[J]); }
+    std::vector<SpRec> recs_level((size_t)nsn);
+    {
+        std::vector<int> pos_of((size_t)nsn);
+        for (int tn = 0; tn < nsn; ++tn) pos_of[(size_t)tasknode[(size_t)tn]] = tn;
+        lvlptr.assign((size_t)nlev + 1, 0);
+        for (int J = 0; J < nsn; ++J) lvlptr[(size_t)lvl[J]]++;
+        for (int l = 0; l < nlev; ++l) lvlptr[(size_t)l + 1] += lvlptr[(size_t)l];
+        std::vector<int> nx(lvlptr.begin(), lvlptr.end() - 1);
+        for (int J = 0; J < nsn; ++J) recs_level[(size_t)nx[(size_t)lvl[J] - 1]++] = recs[(size_t)pos_of[(size_t)J]];
+    }
+    h->sp_lvlptr = lvlptr;
     // ---- product lists: slot e of the panel values <- sum_t fcoef[t] d[fcol[t]]
     const int64_t nslot = S.lptr[nsn];
     std::vector<int> fptr((size_t)nslot + 1, 0), fcol;
@@ -668,6 +686,8 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     SpRec* d_rec = nullptr;
     if ((rc = sp_upload(h, recs, &d_rec))) return rc;
     F.rec = d_rec;
+    if ((rc = sp_upload(h, recs_level, &h->sp_rec_level))) return rc;
+    h->sp_level_mode = (getenv("IPM_SP_MODE") && !strcmp(getenv("IPM_SP_MODE"), "level")) ? 1 : 0;
     if ((rc = sp_upload(h, nodes, &d_node))) return rc;
     if ((rc = sp_upload(h, S.rows, &d_rows))) return rc;
     if ((rc = sp_upload(h, S.child, &d_child))) return rc;
@@ -1119,11 +1139,26 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
 static int enqueue_group_inverses(ipm_handle* h, int g0, int g1, hipStream_t st);
 static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1, int ginv_step = -1) {
     if (sp_on(h)) {                     // multifrontal sparse Cholesky: one launch walks the elimination tree
-#define SP_LAUNCH_CHOL(NT, SC)                                                                                                    \
-    hipLaunchKernelGGL((sp_chol_kernel<NT, SC>), dim3(sp_launch_grid(h)), dim3(NT), h->sp_lds_chol, h->stream, h->spF, ++h->sp_epoch, \
-                       &h->sc->maxdiag, h->opt.pivot_guard_eps, h->opt.pivot_guard_big, h->shift_rel, &h->sc->fixed, h->sp_lds_doubles)
-        if (h->sp_threads == 64) { if (h->sp_sc1) SP_LAUNCH_CHOL(64, true); else SP_LAUNCH_CHOL(64, false); }
-        else { if (h->sp_sc1) SP_LAUNCH_CHOL(SPC_THREADS, true); else SP_LAUNCH_CHOL(SPC_THREADS, false); }
+#define SP_LAUNCH_CHOL(NT, SC, GRID, RECS, COUNT)                                                                                  \
+    hipLaunchKernelGGL((sp_chol_kernel<NT, SC>), dim3(GRID), dim3(NT), h->sp_lds_chol, h->stream, h->spF, ep, &h->sc->maxdiag,       \
+                       h->opt.pivot_guard_eps, h->opt.pivot_guard_big, h->shift_rel, &h->sc->fixed, h->sp_lds_doubles, RECS, COUNT)
+#define SP_CHOL(GRID, RECS, COUNT)                                                                                                   \
+    do {                                                                                                                             \
+        if (h->sp_threads == 64) { if (h->sp_sc1) SP_LAUNCH_CHOL(64, true, GRID, RECS, COUNT); else SP_LAUNCH_CHOL(64, false, GRID, RECS, COUNT); } \
+        else { if (h->sp_sc1) SP_LAUNCH_CHOL(SPC_THREADS, true, GRID, RECS, COUNT); else SP_LAUNCH_CHOL(SPC_THREADS, false, GRID, RECS, COUNT); } \
+    } while (0)
+        const unsigned ep = ++h->sp_epoch;
+        if (h->sp_level_mode && !h->sp_serial) {
+            // one launch per level of the panel tree, leaves first: the kernel boundary is the hand-off (~5 us against ~8-20 us
+            // for a flag hand-off inside one launch), nothing spins, and concurrent handles interleave at launch granularity
+            for (size_t l = 0; l + 1 < h->sp_lvlptr.size(); ++l) {
+                const int cnt = h->sp_lvlptr[l + 1] - h->sp_lvlptr[l];
+                SP_CHOL((unsigned)std::min(cnt, h->sp_grid), h->sp_rec_level + h->sp_lvlptr[l], cnt);
+            }
+        } else {
+            SP_CHOL(sp_launch_grid(h), h->spF.rec, 0);
+        }
+#undef SP_CHOL
 #undef SP_LAUNCH_CHOL
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
@@ -1405,14 +1440,34 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out, hipEvent
 static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_last = nullptr) {
     if (sp_on(h)) {                     // forward and backward sweep over the elimination tree, one launch each
         const int rm = std::max(16, h->sp_rmax);
-#define SP_LAUNCH_SOLVE(NT, SC)                                                                                                               \
-    do {                                                                                                                                      \
-        hipLaunchKernelGGL((sp_fwd_kernel<NT, SC>), dim3(sp_launch_grid(h)), dim3(NT), h->sp_lds_solve, h->stream, h->spF, ++h->sp_epoch, r, h->t2, rm); \
-        hipLaunchKernelGGL((sp_bwd_kernel<NT, SC>), dim3(sp_launch_grid(h)), dim3(NT), 0, h->stream, h->spF, ++h->sp_epoch, h->t2, out);       \
+#define SP_LAUNCH_FWD(NT, SC, GRID, RECS, COUNT) \
+    hipLaunchKernelGGL((sp_fwd_kernel<NT, SC>), dim3(GRID), dim3(NT), h->sp_lds_solve, h->stream, h->spF, ep, r, h->t2, rm, RECS, COUNT)
+#define SP_LAUNCH_BWD(NT, SC, GRID, RECS, COUNT) \
+    hipLaunchKernelGGL((sp_bwd_kernel<NT, SC>), dim3(GRID), dim3(NT), 0, h->stream, h->spF, ep, h->t2, out, RECS, COUNT)
+#define SP_SWEEP(WHICH, GRID, RECS, COUNT)                                                                                            \
+    do {                                                                                                                             \
+        if (h->sp_threads == 64) { if (h->sp_sc1) WHICH(64, true, GRID, RECS, COUNT); else WHICH(64, false, GRID, RECS, COUNT); }     \
+        else { if (h->sp_sc1) WHICH(SPC_THREADS, true, GRID, RECS, COUNT); else WHICH(SPC_THREADS, false, GRID, RECS, COUNT); }       \
     } while (0)
-        if (h->sp_threads == 64) { if (h->sp_sc1) SP_LAUNCH_SOLVE(64, true); else SP_LAUNCH_SOLVE(64, false); }
-        else { if (h->sp_sc1) SP_LAUNCH_SOLVE(SPC_THREADS, true); else SP_LAUNCH_SOLVE(SPC_THREADS, false); }
-#undef SP_LAUNCH_SOLVE
+        unsigned ep = ++h->sp_epoch;
+        const size_t nlev = h->sp_lvlptr.size() > 0 ? h->sp_lvlptr.size() - 1 : 0;
+        if (h->sp_level_mode && !h->sp_serial) {
+            for (size_t l = 0; l < nlev; ++l) {
+                const int cnt = h->sp_lvlptr[l + 1] - h->sp_lvlptr[l];
+                SP_SWEEP(SP_LAUNCH_FWD, (unsigned)std::min(cnt, h->sp_grid), h->sp_rec_level + h->sp_lvlptr[l], cnt);
+            }
+            for (size_t l = nlev; l-- > 0;) {
+                const int cnt = h->sp_lvlptr[l + 1] - h->sp_lvlptr[l];
+                SP_SWEEP(SP_LAUNCH_BWD, (unsigned)std::min(cnt, h->sp_grid), h->sp_rec_level + h->sp_lvlptr[l], cnt);
+            }
+        } else {
+            SP_SWEEP(SP_LAUNCH_FWD, sp_launch_grid(h), h->spF.rec, 0);
+            ep = ++h->sp_epoch;
+            SP_SWEEP(SP_LAUNCH_BWD, sp_launch_grid(h), h->spF.rec, 0);
+        }
+#undef SP_SWEEP
+#undef SP_LAUNCH_FWD
+#undef SP_LAUNCH_BWD
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }
@@ -1590,7 +1645,7 @@ static int enqueue_snapshot(ipm_handle* h, int restore) {
     return IPM_OK;
 }
 // can the next factorization time out at all?  (mirrors the `fs` rule of enqueue_factor)
-static bool may_poll(const ipm_handle* h) { return (h->spf && !h->sp_serial) || h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
+static bool may_poll(const ipm_handle* h) { return (h->spf && !h->sp_serial && !h->sp_level_mode) || h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
 
 static void fill_stats(ipm_handle* h, ipm_stats* st, double ms) {
     if (!st) return;

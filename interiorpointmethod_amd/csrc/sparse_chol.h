@@ -193,7 +193,11 @@ __global__ __launch_bounds__(256) void sp_maxdiag_kernel(const double* L, const 
 // offsets and those of its children) sits in one record in task order (SpRec), read with uniform loads.
 template <int NT, bool SC1>
 __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch, const double* maxdiag, double eps,
-                                                              double big, double shift_rel, int* fixed, int lds) {
+                                                              double big, double shift_rel, int* fixed, int lds,
+                                                              const SpRec* __restrict__ recs, int lvl_count) {
+    // lvl_count > 0: LEVEL mode -- this launch owns the lvl_count panels recs[0 .. lvl_count) of one level of the tree (all
+    // their children were finished by earlier launches): no task queue, no waits, no flags.  lvl_count == 0: the whole tree in
+    // one launch (recs = f.rec in task order), tasks drawn from the counter, hand-offs through flags.
     if (f.done && *f.done) return;
     extern __shared__ __attribute__((aligned(16))) double P[];
     __shared__ double rs[SPC_WCAP];
@@ -202,18 +206,25 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
     const double md = *maxdiag;
     const double thresh = eps * md, shift = shift_rel * md;
     unsigned* flag = f.flag;
-    const SpRec* __restrict__ recs = f.rec;
+    const bool level = lvl_count > 0;
     int nfix = 0;
-    for (;;) {
-        const int task = sp_next_task(f.ctr, &s_task);
-        if (task >= f.ntask) break;
-        const int tn1 = f.taskptr[task + 1];
-        for (int tn = f.taskptr[task]; tn < tn1; ++tn) {
+    for (int round = 0;; ++round) {
+        int task = 0, tn0, tn1;
+        if (level) {
+            tn0 = (int)blockIdx.x + round * (int)gridDim.x;
+            if (tn0 >= lvl_count) break;
+            tn1 = tn0 + 1;
+        } else {
+            task = sp_next_task(f.ctr, &s_task);
+            if (task >= f.ntask) break;
+            tn0 = f.taskptr[task]; tn1 = f.taskptr[task + 1];
+        }
+        for (int tn = tn0; tn < tn1; ++tn) {
             const SpRec& rc = recs[tn];
             const int r = rc.r, w = rc.w, p = r - w, nchild = rc.nchild;
             const bool front = r * r <= lds;
             const int ldp = front ? r : w;
-            if (rc.wait_children) {
+            if (!level && rc.wait_children) {
                 if (tid < nchild && rc.ch[tid].ext) (void)sp_wait(flag + rc.ch[tid].K, epoch, f.timeout);   // (a time-out poisons the results; the host reruns the launch)
                 sp_consume_barrier<SC1>();
             } else {
@@ -331,18 +342,19 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
             }
             for (int idx = tid; idx < r * w; idx += NT) { const int a = idx / w, b = idx - a * w; Lp[idx] = P[a * ldp + b]; }
             if (tid < w) f.dinv[rc.c0 + tid] = rs[tid];             // 1 / L_cc for the substitutions (a multiply per step instead of a divide)
-            if (rc.publish) sp_signal<SC1>(flag + rc.J, epoch);
+            if (!level && rc.publish) sp_signal<SC1>(flag + rc.J, epoch);
         }
     }
     if (tid == 0 && nfix) atomicAdd(fixed, nfix);
-    sp_leave(f.ctr);
+    if (!level) sp_leave(f.ctr);
 }
 
 // ------------------------------------------------------------------------------------------------------------ L z = rhs
 // z may alias rhs.  Panel J: f = rhs(J's columns) + children's update vectors (child-major, as the factorization);
 // z_J = L_JJ^{-1} f_top; the rows below get f_below - L_21 z_J, handed to the parent.  Dynamic LDS: rmax + 1024 doubles.
 template <int NT, bool SC1>
-__global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, const double* rhs, double* z, int rmax) {
+__global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, const double* rhs, double* z, int rmax,
+                   const SpRec* __restrict__ recs, int lvl_count) {
     if (f.done && *f.done) return;
     extern __shared__ __attribute__((aligned(16))) double fv[];
     double* D = fv + rmax;
@@ -350,15 +362,22 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
     const int tid = threadIdx.x;
     unsigned* flag = f.flag + f.nsn;
     unsigned* ctr = f.ctr + 2;
-    const SpRec* __restrict__ recs = f.rec;
-    for (;;) {
-        const int task = sp_next_task(ctr, &s_task);
-        if (task >= f.ntask) break;
-        const int tn1 = f.taskptr[task + 1];
-        for (int tn = f.taskptr[task]; tn < tn1; ++tn) {
+    const bool level = lvl_count > 0;                        // (see sp_chol_kernel)
+    for (int round = 0;; ++round) {
+        int task = 0, tn0, tn1;
+        if (level) {
+            tn0 = (int)blockIdx.x + round * (int)gridDim.x;
+            if (tn0 >= lvl_count) break;
+            tn1 = tn0 + 1;
+        } else {
+            task = sp_next_task(ctr, &s_task);
+            if (task >= f.ntask) break;
+            tn0 = f.taskptr[task]; tn1 = f.taskptr[task + 1];
+        }
+        for (int tn = tn0; tn < tn1; ++tn) {
             const SpRec& rc = recs[tn];
             const int r = rc.r, w = rc.w, nchild = rc.nchild;
-            if (rc.wait_children) {
+            if (!level && rc.wait_children) {
                 if (tid < nchild && rc.ch[tid].ext) (void)sp_wait(flag + rc.ch[tid].K, epoch, f.timeout);
                 sp_consume_barrier<SC1>();
             } else {
@@ -419,17 +438,17 @@ __global__ __launch_bounds__(NT) void sp_fwd_kernel(SpFactor f, unsigned epoch, 
                     sp_st<SC1>(uv + a, fv[a] - dot);
                 }
             }
-            if (rc.publish) sp_signal<SC1>(flag + rc.J, epoch);
+            if (!level && rc.publish) sp_signal<SC1>(flag + rc.J, epoch);
         }
     }
-    sp_leave(ctr);
+    if (!level) sp_leave(ctr);
 }
 
 // ------------------------------------------------------------------------------------------------------------ L^T x = z
 // x may alias z.  Panels in DESCENDING order: x_J = L_JJ^{-T} (z_J - L_21^T x(rows below)); the rows below belong to
 // ancestors, whose x is final once the parent's flag is up.
 template <int NT, bool SC1>
-__global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, const double* z, double* x) {
+__global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, const double* z, double* x, const SpRec* __restrict__ recs, int lvl_count) {
     if (f.done && *f.done) return;
     constexpr int NSL = NT / 32;
     __shared__ double part[NSL * SPC_WCAP];
@@ -438,16 +457,23 @@ __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, 
     const int tid = threadIdx.x;
     unsigned* flag = f.flag + 2 * f.nsn;
     unsigned* ctr = f.ctr + 4;
-    const SpRec* __restrict__ recs = f.rec;
-    for (;;) {
-        const int draw = sp_next_task(ctr, &s_task);
-        if (draw >= f.ntask) break;
-        const int task = f.ntask - 1 - draw;
-        const int tn0 = f.taskptr[task];
-        for (int tn = f.taskptr[task + 1] - 1; tn >= tn0; --tn) {
+    const bool level = lvl_count > 0;                        // (see sp_chol_kernel; the host launches the levels top down)
+    for (int round = 0;; ++round) {
+        int tn0, tn1;
+        if (level) {
+            tn0 = (int)blockIdx.x + round * (int)gridDim.x;
+            if (tn0 >= lvl_count) break;
+            tn1 = tn0 + 1;
+        } else {
+            const int draw = sp_next_task(ctr, &s_task);
+            if (draw >= f.ntask) break;
+            const int task = f.ntask - 1 - draw;
+            tn0 = f.taskptr[task]; tn1 = f.taskptr[task + 1];
+        }
+        for (int tn = tn1 - 1; tn >= tn0; --tn) {
             const SpRec& rc = recs[tn];
             const int r = rc.r, w = rc.w, p = r - w;
-            if (rc.publish) {                                        // the parent belongs to another task
+            if (!level && rc.publish) {                              // the parent belongs to another task
                 if (tid == 0) (void)sp_wait(flag + rc.parent, epoch, f.timeout);
                 sp_consume_barrier<SC1>();
             } else {
@@ -481,10 +507,10 @@ __global__ __launch_bounds__(NT) void sp_bwd_kernel(SpFactor f, unsigned epoch, 
                     if (tid < w) sp_st<SC1>(x + rc.c0 + tid, ga);
                 }
             }
-            if (rc.wait_children) sp_signal<SC1>(flag + rc.J, epoch);       // some child belongs to another task: it waits for this x
+            if (!level && rc.wait_children) sp_signal<SC1>(flag + rc.J, epoch);       // some child belongs to another task: it waits for this x
         }
     }
-    sp_leave(ctr);
+    if (!level) sp_leave(ctr);
 }
 
 // dense image of the factor (ipm_get_factor): out must be zeroed; one workgroup per panel

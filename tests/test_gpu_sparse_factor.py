@@ -81,8 +81,8 @@ def test_guard_and_shift_match_the_oracle(golden_dir):
 
 
 def test_schedule_independence(golden_dir, monkeypatch):
-    """One workgroup walking the tasks in order (what the library falls back to after a hand-off time-out), a handful, and
-    the full grid give the SAME bits: every sum has a fixed order, whatever the schedule."""
+    """One workgroup walking the tasks in order (what the library falls back to after a hand-off time-out), a handful, the
+    full grid, and the level-by-level launches give the SAME bits: every sum has a fixed order, whatever the schedule."""
     A, b, c = _lp(golden_dir, "STOCFOR2")
     rhs = np.cos(np.arange(A.shape[0]))
     out = []
@@ -93,6 +93,9 @@ def test_schedule_independence(golden_dir, monkeypatch):
             monkeypatch.setenv("IPM_SP_GRID", grid)
         with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
             out.append((sv.normal_solve(rhs), sv.get_factor()))
+    monkeypatch.setenv("IPM_SP_MODE", "level")                # one launch per level of the tree instead of one per sweep
+    with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
+        out.append((sv.normal_solve(rhs), sv.get_factor()))
     for z, L in out[1:]:
         assert np.array_equal(z, out[0][0]) and np.array_equal(L, out[0][1])
 

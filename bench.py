@@ -256,6 +256,11 @@ def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, 
     import torch
     from interiorpointmethod_amd import batch
     costs = [batch.predicted_cost(p[0].shape[0], p[0].shape[1]) for p in probs]
+    order_mode = os.environ.get("IPM_BENCH_ORDER", "")
+    if order_mode:                                   # experiment: where in the queue the sparse-factor LPs go
+        for i, nm in enumerate(names):
+            if PATHS.get(nm) == "sparse":
+                costs[i] = 1e9 + costs[i] if order_mode == "sparse_first" else 1e-3 * costs[i]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

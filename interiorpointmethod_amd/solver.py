@@ -459,7 +459,10 @@ def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=
             probe.normal_solve(np.zeros(probe.m))
             if probe.last_pivots_fixed > 0.05 * probe.m:
                 opts = dict(opts, regularize=1e-14)
+    import time as _time
+    t0 = _time.perf_counter()
     with IpmSolver(A, b, c, device=device, **opts) as sv:
+        t1 = _time.perf_counter()
         if start == "mehrotra":
             sv.set_state(*sv.mehrotra_start())
         elif start == "reference":
@@ -467,10 +470,19 @@ def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=
         else:
             raise ValueError('start must be "reference" or "mehrotra"')
         sv.solve(tol=tol, max_iter=max_iter, tol_gap=tol_gap)
+        t2 = _time.perf_counter()
         x, y, s = sv.get_state()
         info = _info(sv)
         if history:
             info["history"] = sv.history()
+        fac = sv.factor
+    t3 = _time.perf_counter()
+    # host-side phases of the call (seconds): handle creation + upload + symbolic analysis, the solve, read-back + destroy
+    info["setup_seconds"], info["solve_seconds"], info["teardown_seconds"] = t1 - t0, t2 - t1, t3 - t2
+    if os.environ.get("IPM_LP_TIMING"):
+        import sys
+        print("[lp-timing] m=%d factor=%s setup %.3f solve %.3f (device %.3f) teardown %.3f" %
+              (sv.m, fac, t1 - t0, t2 - t1, info["solve_ms"] * 1e-3, t3 - t2), file=sys.stderr, flush=True)
     _last_info = info
     return x, y, s, info
 

@@ -1372,6 +1372,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
                 ++h->n_counter_steps;
             } else ++h->n_event_steps;
             if (h->bulk_variant == 1) HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
+            else if (h->bulk_variant == 3) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // 8 waves per tile
+            else if (h->bulk_variant == 4) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
             else HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
         }
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));

@@ -19,9 +19,12 @@ the fp64-MFMA A D^2 A^T contraction, timed with HIP events on the solver's strea
 timed region) and `cpu_baseline` (the NumPy normal-equations oracle on the host cores,
 bounded sample, rank 0 at N=1 only), `cpu_baseline_reference_algorithm` (one iteration of the
 reference's OWN algorithm -- dense (m+2n) KKT matrix, two LAPACK gesv, main.py:13-21/185-244 --
-restated by the oracle, same rank/N) and `netlib`: the second half of BASELINE.json's metric,
-Netlib LPs/s over the 26-LP parity set on this GPU with its own `roofline` and `cpu_baseline`
-(`--workload netlib` runs the full suite, sharded over the ranks, with the same keys).
+restated by the oracle, same rank/N) and the second half of BASELINE.json's metric on this GPU:
+`netlib_all` = Netlib LPs/s over ALL 73 valid benchmarks/ LPs (BASELINE.json configs[3]) and `netlib`
+= the 26-LP parity set, each with its own `roofline`, `cpu_baseline` (one time-bounded oracle pass)
+and a per-LP table carrying setup/solve/teardown seconds and the library's hidden recoveries
+(`timeouts_recovered`, `serial_launches`).  `--workload netlib` runs a set sharded over the ranks
+with the same keys.
 """
 import argparse
 import json
@@ -52,22 +55,24 @@ def load_traffic(m, n):
     """(traffic bytes per launch | None, note).  HBM-side bytes of the dominant kernel from the newest committed PMC
     pass (tools/pmc_form_kernel.py), accepted only for the same problem size AND the same kernel source."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_form_kernel.json"))):
+    best, other = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_form_kernel*.json"))):
         try:
             with open(f) as fh:
                 d = json.load(fh)
         except Exception:
             continue
-        best = (f, d)
+        if tuple(d.get("shape", ())) == (m, n):
+            best = (f, d)                       # newest pass collected at this problem size
+        else:
+            other = (f, d)
     if best is None:
-        return None, "no PMC pass committed"
+        return None, ("no PMC pass committed" if other is None else
+                      "no PMC pass for %d x %d (newest is %s for shape %s)" % (m, n, os.path.basename(other[0]), other[1].get("shape")))
     f, d = best
     if d.get("kernel_source_sha") != kernel_source_sha():
         return None, "stale: %s was collected for kernel source %s, current is %s" % (
             os.path.basename(f), d.get("kernel_source_sha"), kernel_source_sha())
-    if tuple(d.get("shape", ())) != (m, n):
-        return None, "%s is for shape %s" % (os.path.basename(f), d.get("shape"))
     return d["derived"]["traffic_bytes_per_launch"], "from %s (rocprofv3 --pmc, separate passes)" % os.path.basename(f)
 
 
@@ -119,9 +124,14 @@ def _dist_setup(local_rank, world, want_store=False):
     one-GPU box (every rank on device 0, CPU collectives).  want_store: a TCPStore (public API) for the
     self-scheduling counter of the batched mode, or None when it cannot be set up on every rank."""
     import torch
-    if world <= 1:
+    force = bool(os.environ.get("IPM_BENCH_FORCE_DIST"))      # a process group of ONE rank: exercises the RCCL branch on one GPU
+    if world <= 1 and not force:
         return None, local_rank, "cuda", None
     import torch.distributed as dist
+    if world <= 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        world = 1
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("IPM_BENCH_BACKEND", "nccl")
     dev = 0 if os.environ.get("IPM_BENCH_ONE_DEVICE") else local_rank
@@ -152,6 +162,7 @@ PARITY_SET = ["AFIRO", "BANDM", "DEGEN2", "E226", "FIT1P", "GROW15", "GROW22", "
 
 
 PATHS = {}          # LP name -> "sparse" | "dense": the factorization path IpmSolver's rule picks (filled by load_netlib)
+ORDER_INFO = {}     # LP name -> ipm_order_rows info (panel tree height, critical-path area) for the sparse-path LPs
 
 
 def load_netlib(which, max_m=1 << 30):
@@ -173,6 +184,9 @@ def load_netlib(which, max_m=1 << 30):
         names.append(nm); probs.append((A, b, c))
         path, f_chol, f_sweeps = path_flops(A)
         PATHS[nm] = path
+        if path == "sparse":
+            from interiorpointmethod_amd import solver as _S
+            ORDER_INFO[nm] = _S.ORDER_INFO_CACHE.pop(id(A), None)
         flops.append(float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2)) + f_chol + f_sweeps + 12.0 * A.nnz)
 
     if which == "general":
@@ -201,17 +215,29 @@ def load_netlib(which, max_m=1 << 30):
     return names, probs, flops
 
 
+def predicted_ms_per_iteration(name, m):
+    """The fitted per-iteration latency models of DESIGN.md 4-S (solver.prefer_sparse_factor): sparse multifrontal factor
+    0.061 ms per level of the panel tree + 5.56e-6 ms per (front rows)^2 along the critical path (floor 0.3 ms);
+    dense-tile factor 0.1 ms + 0.08 ms per 128-row block; the fused single-workgroup kernel (m <= 128) 0.02 ms."""
+    from interiorpointmethod_amd.solver import FUSED_SMALL_MAX_ROWS
+    if m <= FUSED_SMALL_MAX_ROWS:
+        return 0.02
+    info = ORDER_INFO.get(name)
+    if PATHS.get(name) == "sparse" and info:
+        return max(0.3, -0.13 + 0.061 * info["panel_height"] + 5.56e-6 * info["path_area"])
+    return 0.1 + 0.08 * ((m + 127) // 128)
+
+
 def netlib_roofline(names, probs, flops, rec, elapsed, world):
-    """Roofline view of a batched run.  Algorithmic flops of an LP = iterations x (sum_j nnz(A[:,j])^2 + Cholesky + 4 m^2
-    + 12 nnz) (SURVEY 8d with the sparse contraction count; the Cholesky term is m^3/3, or the flops inside the tile
-    envelope where the device exploits it -- solver.factor_flops).  The suite is NOT flop bound: every iteration is a
-    chain of dependent launches (measured cost model 0.1 ms + 0.11 ms per 128-row block, batch.predicted_cost), so
-    the latency model's prediction is printed beside the MFMA fraction."""
+    """Roofline view of a batched run.  Algorithmic flops of an LP = iterations x (sum_j nnz(A[:,j])^2 + Cholesky + sweeps
+    + 12 nnz) (SURVEY 8d with the sparse contraction count; the Cholesky term as the device runs it, solver.path_flops).
+    The suite is NOT flop bound: every iteration is a chain of dependent steps (pivot blocks / levels of the panel tree),
+    so the prediction of the two fitted latency models (predicted_ms_per_iteration) is printed beside the MFMA fraction."""
     import numpy as np
     its = rec[:, 2]
     total = float(np.sum(its * np.array(flops)))
-    nblk = np.array([(p[0].shape[0] + 127) // 128 for p in probs], dtype=np.float64)
-    chain_s = float(np.sum(its * (0.1 + 0.11 * nblk)) * 1e-3)
+    ms_it = np.array([predicted_ms_per_iteration(nm, p[0].shape[0]) for nm, p in zip(names, probs)])
+    per_lp_s = its * ms_it * 1e-3
     ach = total / elapsed / 1e12
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS * max(world, 1), "unit": "TFLOP/s",
             "frac": ach / (PEAK_FP64_MFMA_TFLOPS * max(world, 1)), "traffic": None,
@@ -221,33 +247,68 @@ def netlib_roofline(names, probs, flops, rec, elapsed, world):
                     "count^2; dense-tile factor: m^3/3, or inside the tile envelope] + sweeps [4 nnz(L) or 4 m^2] + 12 nnz) / "
                     "wall / (78.6 TFLOP/s x GPUs); the suite is bound by dependent steps (pivot chain / elimination-tree "
                     "levels), not by flops",
-            "latency_floor": {"model": "iterations x (0.1 ms + 0.11 ms per 128-row block) summed over the LPs, one LP at a "
-                                       "time on one GPU (round-1 measurement, batch.predicted_cost)",
-                              "chain_seconds_one_gpu": chain_s, "measured_wall_seconds": elapsed,
-                              "largest_lp_seconds": float(rec[:, 7].max())}}
+            "latency_floor": {"model": "iterations x fitted ms per iteration, one LP at a time with the look-ahead (DESIGN 4-S: "
+                                       "sparse factor max(0.3, -0.13 + 0.061 panel-tree levels + 5.56e-6 critical-path area); "
+                                       "dense-tile factor 0.1 + 0.08 per 128-row block; fused small-LP kernel 0.02)",
+                              "chain_seconds_one_gpu": float(per_lp_s.sum()),
+                              "largest_lp_predicted_seconds": float(per_lp_s.max()) if len(per_lp_s) else 0.0,
+                              "largest_lp_predicted": names[int(np.argmax(per_lp_s))] if len(per_lp_s) else None,
+                              "measured_wall_seconds": elapsed,
+                              "largest_lp_seconds": float(rec[:, 7].max()),
+                              "largest_lp": names[int(rec[int(np.argmax(rec[:, 7])), 0])]}}
 
 
-def netlib_cpu_baseline(names, probs, budget_s=15.0, tol_gap=None, max_iter=300):
-    """The oracle (normal equations + guarded Cholesky, the algorithm the GPU runs) over a BOUNDED sample of the same
-    set on the host: smallest LPs first until the time budget is spent, one process, BLAS threads as configured."""
+def per_lp_table(names, rec):
+    """Per-LP view of the gathered records: status, iterations, objective, wall seconds and its host-side split, and the
+    library's hidden recoveries (batch.RECORD_FIELDS)."""
+    return {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3),
+                               "setup_s": round(r[11], 3), "solve_s": round(r[12], 3), "teardown_s": round(r[13], 3),
+                               "timeouts_recovered": int(r[9]), "serial_launches": int(r[10])} for r in rec}
+
+
+def netlib_cpu_baseline(names, probs, budget_s=20.0, tol_gap=None, max_iter=300):
+    """The oracle (normal equations + guarded Cholesky, the algorithm the GPU runs) over a sample of the same set on the
+    host, BOUNDED BY TIME: smallest LPs first; an LP is started only while its predicted cost (dense m x m Cholesky +
+    formation per iteration at a few GFLOP/s effective, 60 iterations) fits what is left of the budget, and the loop
+    ends at the budget.  One process, BLAS threads as configured.  Returns the per-LP seconds too, so that a subset (the
+    parity set inside the full suite) can be reported from the same pass."""
     import numpy as np
     from oracle import ipm_oracle as O
     order = sorted(range(len(names)), key=lambda i: (probs[i][0].shape[0] * probs[i][0].shape[1], names[i]))
-    done, conv, t0 = [], 0, time.perf_counter()
+    done, per, skipped, t0 = [], {}, [], time.perf_counter()
     for i in order:
-        # bounded: stop at the budget, and never start an LP whose dense m x m factor makes one solve take minutes
-        if time.perf_counter() - t0 > budget_s or probs[i][0].shape[0] > 1200:
+        left = budget_s - (time.perf_counter() - t0)
+        if left <= 0:
             break
         A, b, c = probs[i]
+        m, n = A.shape
+        predicted = 60.0 * (m ** 3 / 3.0 + 2.0 * m * m * min(n, 50 * m) * 0.02) / 5e9      # crude: skip what cannot fit
+        if predicted > left:
+            skipped.append(names[i])
+            continue
+        t1 = time.perf_counter()
         x, y, s, info = O.solve(A, b, c, tol=1e-8, y0=1.0, method="normal", max_iter=max_iter, tol_gap=tol_gap)
-        done.append(names[i]); conv += int(info["status"] == O.STATUS_OK)
+        per[names[i]] = (time.perf_counter() - t1, int(info["status"] == O.STATUS_OK))
+        done.append(names[i])
     dt = time.perf_counter() - t0
-    return {"value": conv / dt, "unit": "LPs/s", "cores": _blas_threads(), "kind": "port",
-            "sample": "oracle.solve(method='normal') on the %d smallest LPs of the set (%s ... %s), %d converged, %.1f s, "
-                      "one process; reference verbatim loop in the survey container: 26 LPs in 603 s = 0.043 LPs/s "
-                      "per worker (BASELINE.md 2.4)" % (len(done), done[0] if done else "-", done[-1] if done else "-",
-                                                        conv, dt),
-            "sample_names": done}
+    conv = sum(v[1] for v in per.values())
+    return {"value": conv / dt if dt > 0 else 0.0, "unit": "LPs/s", "cores": _blas_threads(), "kind": "port",
+            "sample": "oracle.solve(method='normal') smallest-first over the set within a %.0f s budget: %d LPs solved (%s ... %s), "
+                      "%d converged, %.1f s, one process; not started (predicted beyond the budget): %d LPs; reference verbatim "
+                      "loop in the survey container: 26 LPs in 603 s = 0.043 LPs/s per worker (BASELINE.md 2.4)" % (
+                          budget_s, len(done), done[0] if done else "-", done[-1] if done else "-", conv, dt, len(skipped)),
+            "sample_names": done, "seconds_per_lp": {k: round(v[0], 4) for k, v in per.items()},
+            "converged_per_lp": {k: v[1] for k, v in per.items()}}
+
+
+def cpu_baseline_subset(cb, subset):
+    """The view of one netlib_cpu_baseline pass restricted to the LPs of `subset` (same timings, no second run)."""
+    nm = [k for k in cb["sample_names"] if k in subset]
+    dt = sum(cb["seconds_per_lp"][k] for k in nm)
+    conv = sum(cb["converged_per_lp"][k] for k in nm)
+    return {"value": conv / dt if dt > 0 else 0.0, "unit": "LPs/s", "cores": cb["cores"], "kind": "port",
+            "sample": "the %d LPs of this set inside the time-bounded oracle pass over the full suite (netlib_all.cpu_baseline): "
+                      "%d converged in %.1f s" % (len(nm), conv, dt), "sample_names": nm}
 
 
 def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, workers=2, schedule="dynamic",
@@ -266,6 +327,7 @@ def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, 
         dist.barrier()
     t0 = time.perf_counter()
     rec, _ = batch.run_batch(probs, costs=costs, device=dev, dist=dist, store=store,
+                             collective_at_world_one=bool(os.environ.get("IPM_BENCH_FORCE_DIST")),
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
                              tol=1e-8, regularize=regularize, workers=workers, schedule=schedule, start=start,
                              # the general-form driver's own settings: e3 = 1e-6, at most 999 iterations (main.py:1088-1127)
@@ -295,12 +357,19 @@ def netlib_main(args):
     general = args.netlib_set == "general"
     # warm-up: one small solve per rank (library load, first-launch costs) outside the timed region
     batch.solve_one(probs[names.index("AFIRO")] if "AFIRO" in names else probs[0], device=dev)
+    if os.environ.get("IPM_DUMP_MAPS"):
+        # diagnostic for a profiled run (tools/prof_suite.sh): the address map of this process after every library is
+        # loaded, so that a raw stack trace of a fault under rocprofv3 can be symbolised afterwards
+        with open("/proc/self/maps") as fi, open(os.environ["IPM_DUMP_MAPS"], "w") as fo:
+            fo.write(fi.read())
     rec, elapsed = run_netlib(names, probs, flops, dev, dist=dist, red_dev=red_dev, store=store, workers=args.workers,
                               schedule=args.schedule, start=args.start, regularize=args.regularize, general=general)
     if rank == 0:
         summ = batch.summarize(rec)
-        sched = "one rank" if world <= 1 else ("self-scheduled from a shared counter (TCPStore)"
-                                               if (args.schedule == "dynamic" and store is not None) else "static LPT partition")
+        sched = "one rank" if dist is None else ("self-scheduled from a shared counter (TCPStore)"
+                                                 if (args.schedule == "dynamic" and store is not None) else "static LPT partition")
+        if dist is not None:
+            sched += ", records through dist.all_gather (backend %s, world %d)" % (dist.get_backend(), max(world, 1))
         out = {"metric": "Netlib LPs/sec (benchmarks_full/ general-form suite, batched, tol=1e-8, e3=1e-6, cap 999)"
                          if general else "Netlib LPs/sec (benchmarks/ suite, batched, tol=1e-8, cap 300)",
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
@@ -310,8 +379,7 @@ def netlib_main(args):
                    args.netlib_set, len(names), max(world, 1), sched, max(1, args.workers))},
                "roofline": netlib_roofline(names, probs, flops, rec, elapsed, world),
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize, "start_point": args.start,
-               "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)}
-                          for r in rec}}
+               "per_lp": per_lp_table(names, rec)}
         if world == 1 and not args.no_cpu_baseline:
             cb = netlib_cpu_baseline(names, probs, tol_gap=1e-6 if general else None, max_iter=999 if general else 300)
             cb["gpu_seconds_same_sample"] = float(sum(r[7] for r in rec if names[int(r[0])] in cb["sample_names"]))
@@ -414,8 +482,9 @@ def main():
             "value": its_per_s, "unit": "iterations/s", "n_gpus": ngpu, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "dense synthetic LP m=%d n=%d fp64, seed 0, start x=s=1 y=0 "
-                                   "(BASELINE.json configs[1]); replicas per GPU" % (m, n),
+            "config": {"workload": "dense synthetic LP m=%d n=%d fp64, seed 0, start x=s=1 y=0 (%s); replicas per GPU" % (
+                           m, n, {(4096, 8192): "BASELINE.json configs[1]", (16384, 32768): "BASELINE.json configs[4]"}.get(
+                               (m, n), "not a BASELINE.json config: size sweep")),
                        "reset_every": RESET_EVERY},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
@@ -434,53 +503,72 @@ def main():
                                 "frac_of_fp64_mfma_peak": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12 / PEAK_FP64_MFMA_TFLOPS},
             "objective_after_last_block": st["objective"],
         }
-        # guard against a fast-but-wrong kernel variant (checked when the last block is a full one): at the default
-        # size the objective after RESET_EVERY iterations is compared with the REFERENCE's own trajectory
-        # (tests/golden/dense_syn_4096x8192.npz, generated by importing the reference); at other sizes with the same
-        # iterations under the one-level factorization (IPM_TWO_LEVEL=0) on a second handle
+        # guard against a fast-but-wrong kernel variant, on EVERY run: the objective after the first min(steps, 20)
+        # iterations from the start point (its own untimed pass when the last timed block was a partial one) is compared
+        # at the default size with the REFERENCE's own trajectory (tests/golden/dense_syn_4096x8192.npz, generated by
+        # importing the reference); at other sizes with the same iterations under the one-level factorization
+        # (IPM_TWO_LEVEL=0, no overlapped formation) on a second handle
+        kchk = min(args.steps, RESET_EVERY)
         if args.steps % RESET_EVERY == 0:
-            fx = os.path.join(ROOT, "tests", "golden", "dense_syn_%dx%d.npz" % (m, n))
-            if os.path.exists(fx):
-                ref_obj = float(np.load(fx)["objective_after_iteration"][RESET_EVERY - 1])
-                ok = abs(st["objective"] - ref_obj) <= 1e-6 * max(1.0, abs(ref_obj))
-                out["objective_check"] = "ok" if ok else "MISMATCH"
-                out["objective_check_against"] = "reference trajectory, iteration %d: %.12e" % (RESET_EVERY, ref_obj)
-            else:
-                sv.close()
-                os.environ["IPM_TWO_LEVEL"] = "0"
-                sv1 = ipm.IpmSolver(A, b, c, device=dev)
-                sv1.init_state(0.0)
-                st1 = sv1.iterate(RESET_EVERY)
-                ref_obj = st1["objective"]
-                sv1.close()
-                del os.environ["IPM_TWO_LEVEL"]
-                ok = abs(st["objective"] - ref_obj) <= 1e-9 * max(1.0, abs(ref_obj))
-                out["objective_check"] = "ok" if ok else "MISMATCH"
-                out["objective_check_against"] = "same %d iterations with IPM_TWO_LEVEL=0: %.12e" % (RESET_EVERY, ref_obj)
-            if not ok:
-                print("bench: objective after %d iterations is %.12e, expected %.12e" % (RESET_EVERY, st["objective"], ref_obj),
-                      file=sys.stderr)
+            obj_chk = st["objective"]
+        else:
+            sv.set_profiling(0)
+            sv.init_state(0.0)
+            obj_chk = sv.iterate(kchk)["objective"]
+        fx = os.path.join(ROOT, "tests", "golden", "dense_syn_%dx%d.npz" % (m, n))
+        if os.path.exists(fx):
+            ref_obj = float(np.load(fx)["objective_after_iteration"][kchk - 1])
+            ok = abs(obj_chk - ref_obj) <= 1e-6 * max(1.0, abs(ref_obj))
+            out["objective_check_against"] = "reference trajectory, iteration %d: %.12e" % (kchk, ref_obj)
+        else:
+            sv.close()
+            saved = {k: os.environ.get(k) for k in ("IPM_TWO_LEVEL", "IPM_FUSED_FACTOR")}
+            os.environ["IPM_TWO_LEVEL"] = "0"; os.environ["IPM_FUSED_FACTOR"] = "0"
+            sv1 = ipm.IpmSolver(A, b, c, device=dev)
+            sv1.init_state(0.0)
+            ref_obj = sv1.iterate(kchk)["objective"]
+            sv1.close()
+            for k, v in saved.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+            ok = abs(obj_chk - ref_obj) <= 1e-9 * max(1.0, abs(ref_obj))
+            out["objective_check_against"] = "same %d iterations with IPM_TWO_LEVEL=0 IPM_FUSED_FACTOR=0: %.12e" % (kchk, ref_obj)
+        out["objective_check"] = "ok" if ok else "MISMATCH"
+        out["objective_checked"] = obj_chk
+        if not ok:
+            print("bench: objective after %d iterations is %.12e, expected %.12e" % (kchk, obj_chk, ref_obj), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(A, b, c)
             if (m, n) == (M_DEFAULT, N_DEFAULT):
                 out["cpu_baseline_reference_algorithm"] = cpu_baseline_reference_algorithm(A, b, c)
         if world == 1 and not args.no_netlib and (m, n) == (M_DEFAULT, N_DEFAULT):
-            # second half of the headline metric on the same GPU: the 26-LP parity set, eight LPs in flight (one stream each)
+            # second half of the headline metric on the same GPU, eight LPs in flight (one stream each):
+            #   netlib_all = the metric's own config, BASELINE.json configs[3]: ALL 73 valid benchmarks/ LPs (the loop of
+            #                script.py:147-173 over the suite);
+            #   netlib     = the 26-LP parity set (the files on which the reference itself converges).
             sv.close()
             from interiorpointmethod_amd import batch
-            names, probs, flops = load_netlib("parity")
+            names, probs, flops = load_netlib("all")
             batch.solve_one(probs[names.index("AFIRO")], device=dev)         # warm-up
-            rec, el = run_netlib(names, probs, flops, dev, workers=8)
-            summ = batch.summarize(rec)
-            out["netlib"] = {"metric": "Netlib LPs/sec (26-LP parity set of benchmarks/, tol=1e-8, cap 300, 8 LPs in flight)",
-                             "value": summ["converged"] / el, "unit": "LPs/s", "n_gpus": 1, "wall_seconds": el,
-                             "summary": summ, "roofline": netlib_roofline(names, probs, flops, rec, el, 1),
-                             "per_lp": {names[int(r[0])]: {"status": int(r[1]), "it": int(r[2]), "obj": r[3], "s": round(r[7], 3)} for r in rec}}
-            if not args.no_cpu_baseline:
-                cb = netlib_cpu_baseline(names, probs)
-                # the same LPs on the GPU (their share of the run above; eight LPs were in flight, so this is an upper bound)
-                cb["gpu_seconds_same_sample"] = float(sum(r[7] for r in rec if names[int(r[0])] in cb["sample_names"]))
-                out["netlib"]["cpu_baseline"] = cb
+            cb_all = None if args.no_cpu_baseline else netlib_cpu_baseline(names, probs)
+            for key, label in (("netlib_all", "all 73 valid LPs of benchmarks/ (BASELINE.json configs[3])"),
+                               ("netlib", "26-LP parity set of benchmarks/")):
+                if key == "netlib":
+                    keep = [i for i, nm in enumerate(names) if nm in PARITY_SET]
+                    names, probs, flops = [names[i] for i in keep], [probs[i] for i in keep], [flops[i] for i in keep]
+                rec, el = run_netlib(names, probs, flops, dev, workers=8)
+                summ = batch.summarize(rec)
+                out[key] = {"metric": "Netlib LPs/sec (%s, tol=1e-8, cap 300, 8 LPs in flight)" % label,
+                            "value": summ["converged"] / el, "unit": "LPs/s", "n_gpus": 1, "wall_seconds": el,
+                            "summary": summ, "roofline": netlib_roofline(names, probs, flops, rec, el, 1),
+                            "per_lp": per_lp_table(names, rec)}
+                if cb_all is not None:
+                    cb = dict(cb_all) if key == "netlib_all" else cpu_baseline_subset(cb_all, set(names))
+                    # the same LPs on the GPU (their share of the run above; eight LPs were in flight, so this is an upper bound)
+                    cb["gpu_seconds_same_sample"] = float(sum(r[7] for r in rec if names[int(r[0])] in cb["sample_names"]))
+                    out[key]["cpu_baseline"] = cb
         print(json.dumps(out))
     sv.close()
     if dist is not None:

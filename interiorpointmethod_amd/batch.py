@@ -16,8 +16,15 @@ import time
 
 import numpy as np
 
-RECORD_FIELDS = ("id", "status", "iterations", "objective", "rp", "rd", "gap", "seconds", "pivots_fixed")
+# One record per LP.  The first nine fields are the statistics SURVEY.md 8e names; the rest make the library's hidden
+# recoveries and the host-side phases of a solve visible in the gathered table: `timeouts_recovered` = device hand-off
+# polls that gave up and were rolled back and repeated (ipm_get_schedule), `serial_launches` = sparse-factor sweeps
+# that ran as ONE workgroup after such a time-out (ipm_get_factor_info), setup / solve / teardown = host seconds of
+# handle creation + upload + symbolic analysis, of ipm_solve, and of read-back + destroy (solver.solve_with_info).
+RECORD_FIELDS = ("id", "status", "iterations", "objective", "rp", "rd", "gap", "seconds", "pivots_fixed",
+                 "timeouts_recovered", "serial_launches", "setup_seconds", "solve_seconds", "teardown_seconds")
 NF = len(RECORD_FIELDS)
+_OPTIONAL = RECORD_FIELDS[9:]          # a custom solve_fn need not report these (0 then)
 STATUS_INVALID_INPUT = -6.0          # IPM_ERR_INVALID_INPUT surfaced as a status
 STATUS_ERROR = -99.0
 
@@ -48,6 +55,13 @@ def lpt_partition(costs, world):
 def _error_info(status=STATUS_ERROR):
     nan = float("nan")
     return dict(status=status, iterations=0, objective=nan, rp=nan, rd=nan, gap=nan, pivots_fixed=0)
+
+
+def _row(i, info):
+    """info dict of one solve -> its record row."""
+    return [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]), float(info["rp"]),
+            float(info["rd"]), float(info["gap"]), float(info["seconds"]), float(info["pivots_fixed"])] + \
+           [float(info.get(k, 0.0)) for k in _OPTIONAL]
 
 
 def _guarded(solve_fn, problem, **kw):
@@ -119,9 +133,7 @@ def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
         else:
             info = _guarded(solve_fn, problems[i], device=device, **kw)
         info.setdefault("seconds", time.perf_counter() - t0)
-        rec[row] = [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]),
-                    float(info["rp"]), float(info["rd"]), float(info["gap"]), float(info["seconds"]),
-                    float(info["pivots_fixed"])]
+        rec[row] = _row(i, info)
 
     rows = list(enumerate(ids))
     if workers <= 1:
@@ -140,8 +152,8 @@ def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
 
 def gather_records(local, shard_sizes, dist=None, device=None):
     """All ranks obtain all records, ordered by LP id.  One all_gather of (max_shard, NF) float64
-    tensors (padded with id = -1); ~72 B per LP, latency-bound, xGMI bandwidth irrelevant."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    tensors (padded with id = -1); 8 NF = 112 B per LP, latency-bound, xGMI bandwidth irrelevant."""
+    if dist is None or not dist.is_initialized():
         out = local
     else:
         import torch
@@ -200,9 +212,7 @@ def _solve_dynamic(problems, order, store, key, device, solve_fn, workers, **kw)
             else:
                 info = _guarded(solve_fn, problems[i], device=device, **kw)
             info.setdefault("seconds", time.perf_counter() - t0)
-            rec[i] = [float(i), float(info["status"]), float(info["iterations"]), float(info["objective"]),
-                      float(info["rp"]), float(info["rd"]), float(info["gap"]), float(info["seconds"]),
-                      float(info["pivots_fixed"])]
+            rec[i] = _row(i, info)
 
     if workers <= 1:
         loop(0)
@@ -230,21 +240,25 @@ def _gather_sparse(rec, dist, device=None):
 
 
 def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1,
-              schedule="static", store=None, **kw):
+              schedule="static", store=None, collective_at_world_one=False, **kw):
     """Shard `problems` (list of (A, b, c)) over the ranks of `dist`, solve, gather statistics.
 
     schedule="static": deterministic LPT partition on the predicted cost, no scheduling traffic at all.
     schedule="dynamic" (N > 1): the ranks pull LPs, most expensive first, from a counter on `store` (a
     torch.distributed store shared by all ranks, e.g. make_store(); without one the schedule is "static").  Either way the only collective is
     ONE all-gather of the statistics records.  Returns (records sorted by id, this rank's wall seconds).  Without an
-    initialised process group this is the single-GPU loop."""
+    initialised process group this is the single-GPU loop; so it is with a group of ONE rank, unless
+    collective_at_world_one asks for the distributed code path anyway (store counter, device tensors through
+    dist.all_gather): that is how the RCCL branch is exercised on a one-GPU box (tests/test_gpu_parity.py)."""
     global _CALLS
     _CALLS += 1
-    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
-    rank = dist.get_rank() if world > 1 else 0
+    live = dist is not None and dist.is_initialized()
+    world = dist.get_world_size() if live else 1
+    multi = world > 1 or (live and collective_at_world_one)
+    rank = dist.get_rank() if live else 0
     if costs is None:
         costs = [predicted_cost(p[0].shape[0], p[0].shape[1]) for p in problems]
-    store = store if (world > 1 and schedule == "dynamic") else None
+    store = store if (multi and schedule == "dynamic") else None
     t0 = time.perf_counter()
     if store is not None:
         order = sorted(range(len(problems)), key=lambda i: (-float(costs[i]), i))
@@ -254,7 +268,7 @@ def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, sol
     shards = lpt_partition(costs, world)
     local = solve_shard(problems, shards[rank], device=device, solve_fn=solve_fn, workers=workers, **kw)
     seconds = time.perf_counter() - t0
-    records = gather_records(local, [len(s) for s in shards], dist=dist if world > 1 else None,
+    records = gather_records(local, [len(s) for s in shards], dist=dist if multi else None,
                              device=gather_device)
     return records, seconds
 
@@ -267,4 +281,7 @@ def summarize(records):
                 nan=int((status == 3.0).sum()), invalid=int((status == STATUS_INVALID_INPUT).sum()),
                 errors=int((status == STATUS_ERROR).sum()),
                 total_iterations=int(records[:, 2].sum()), solve_seconds_sum=float(records[:, 7].sum()),
-                pivots_fixed=int(records[:, 8].sum()))
+                pivots_fixed=int(records[:, 8].sum()),
+                timeouts_recovered=int(records[:, 9].sum()), serial_launches=int(records[:, 10].sum()),
+                setup_seconds_sum=float(records[:, 11].sum()), device_solve_seconds_sum=float(records[:, 12].sum()),
+                teardown_seconds_sum=float(records[:, 13].sum()))

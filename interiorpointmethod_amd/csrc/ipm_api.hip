@@ -108,7 +108,8 @@ struct ipm_handle {
     int sp_height = 0, sp_rmax = 0, sp_grid = 1, sp_serial_launches = 0, sp_nvirtual = 0;
     size_t sp_lds_chol = 0, sp_lds_solve = 0;
     int sp_lds_doubles = 16, sp_threads = 256;
-    int sp_level_mode = 0;                // 1 (IPM_SP_MODE=level): one launch per level of the panel tree, no in-kernel hand-offs; 0: one launch per sweep
+    int sp_level_mode = 0;                // 1 (IPM_SP_MODE=level): one launch per level of the panel tree, no in-kernel hand-offs; -1 (=task): one
+                                          // launch per sweep even when the device is shared; 0: sp_level() decides
     std::vector<int> sp_lvlptr;           // [levels + 1] into the level-ordered records
     SpRec* sp_rec_level = nullptr;
     bool sp_sc1 = false;                  // IPM_SP_SC1=1: write-through stores + sc1 loads instead of the release / acquire fence pair
@@ -129,6 +130,8 @@ struct ipm_handle {
     double *y = nullptr, *b = nullptr, *rb = nullptr, *t1 = nullptr, *t2 = nullptr, *dya = nullptr, *dy = nullptr;
     double *atp = nullptr, *part = nullptr, *slab = nullptr;
     int form_variant = 0;
+    const int* fdone = nullptr;           // `done` word the formation / factorization kernels test (null: Scalars::done; the overlapped
+                                          // path points it at the per-iteration latch Scalars::done_f)
     // Tile envelope (skyline) of A A^T for sparse handles, from the structure of A in the caller's row order:
     // env_last[k] = last 128-row block with a structural nonzero at or left of column block k (monotone).  Blocks
     // below it are exactly zero in B and stay zero in L, so the panel solves, trailing updates and triangular
@@ -181,17 +184,34 @@ static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * 
 // of a handle's ~30 frees waited for the other LPs' queued iterations -- measured in the 73-LP suite: STOCFOR3 0.46 s of
 // solve and 1.14 s of teardown, SIERRA 0.12 s and 1.19 s.  IPM_ASYNC_ALLOC=0 restores hipMalloc / hipFree.
 static std::atomic<int> g_pool_state[64];       // per device: 0 unknown, 1 stream-ordered allocation available, 2 not
+static hipMemPool_t g_pool[64];                 // the library's OWN pool per device (never the device's default pool: its
+                                                // attributes belong to the host application)
+static std::mutex g_pool_mutex;
 static bool async_alloc_ok(int device) {
     if (device < 0 || device >= 64) return false;
     int st = g_pool_state[device].load(std::memory_order_acquire);
     if (st == 0) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        st = g_pool_state[device].load(std::memory_order_acquire);
+        if (st != 0) return st == 1;
         int supported = 0;
         const char* e = getenv("IPM_ASYNC_ALLOC");
         if (!(e && atoi(e) == 0) && hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported) {
+            hipMemPoolProps props;
+            memset(&props, 0, sizeof props);
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = device;
             hipMemPool_t pool = nullptr;
-            if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
-                uint64_t keep = UINT64_MAX;             // freed blocks stay in the pool: the next handle reuses them
+            if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+                // freed blocks stay in the pool up to this many bytes, so the next handle reuses them (the sparse factor of
+                // one LP is ~20 blocks); beyond it they go back to the device at the next synchronisation point instead of
+                // staying resident for the life of the process
+                uint64_t keep = (uint64_t)2 << 30;
+                if (const char* k = getenv("IPM_POOL_KEEP_MB")) keep = (uint64_t)atoll(k) << 20;
                 (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                g_pool[device] = pool;
                 st = 1;
             }
         }
@@ -202,7 +222,7 @@ static bool async_alloc_ok(int device) {
 }
 static hipError_t dev_malloc(int device, hipStream_t stream, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
-    if (async_alloc_ok(device)) return hipMallocAsync(p, bytes, stream);
+    if (async_alloc_ok(device)) return hipMallocFromPoolAsync(p, bytes, g_pool[device], stream);
     return hipMalloc(p, bytes);
 }
 static void dev_free(int device, hipStream_t stream, void* p) {
@@ -314,7 +334,7 @@ __global__ void set_params_kernel(Scalars* sc, double e1, double e2, double e3, 
                                   int force, int reset) {
     sc->e1 = e1; sc->e2 = e2; sc->e3 = e3; sc->eta = eta;
     sc->max_iter = max_iter; sc->force = force;
-    sc->done = 0; sc->status = 0;
+    sc->done = 0; sc->done_f = 0; sc->status = 0;
     if (reset) { sc->k = 0; sc->fixed = 0; sc->fixed_first = 0; sc->obj_last_finite = __builtin_nan(""); }
 }
 
@@ -724,7 +744,8 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     if ((rc = sp_upload(h, recs, &d_rec))) return rc;
     F.rec = d_rec;
     if ((rc = sp_upload(h, recs_level, &h->sp_rec_level))) return rc;
-    h->sp_level_mode = (getenv("IPM_SP_MODE") && !strcmp(getenv("IPM_SP_MODE"), "level")) ? 1 : 0;
+    h->sp_level_mode = 0;             // IPM_SP_MODE=level: always one launch per level; =task: never (A/B under contention); unset: sp_level()
+    if (const char* e = getenv("IPM_SP_MODE")) h->sp_level_mode = !strcmp(e, "level") ? 1 : (!strcmp(e, "task") ? -1 : 0);
     if ((rc = sp_upload(h, nodes, &d_node))) return rc;
     if ((rc = sp_upload(h, S.rows, &d_rows))) return rc;
     if ((rc = sp_upload(h, S.child, &d_child))) return rc;
@@ -752,6 +773,19 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     h->sp_lds_chol = sizeof(double) * (size_t)h->sp_lds_doubles;
     h->sp_lds_solve = sizeof(double) * ((size_t)std::max(16, S.rmax) + SPC_WCAP * SPC_WCAP);
     h->sp_threads = threads;
+    if (h->sp_lds_solve > 48 * 1024 || h->sp_lds_chol > 48 * 1024) {
+        // fronts beyond ~5000 rows: the forward sweep's update vector + diagonal block pass the default dynamic-LDS limit
+        const int cap = 96 * 1024;
+        if (h->sp_lds_solve > (size_t)cap || h->sp_lds_chol > (size_t)cap) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: a front of %d rows exceeds the LDS budget of the sweeps", S.rmax);
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<SPC_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<SPC_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<SPC_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<SPC_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    }
     // Fence-free hand-off (write-through stores + sc1 loads) is OPT-IN (IPM_SP_SC1=1): it passes every test and is 8-12 % faster
     // per sweep at STOCFOR3 (0.358 / 0.182 / 0.141 -> 0.328 / 0.161 / 0.132 ms), but this kernel runs several workgroups per CU,
     // outside the configurations that form is documented for; the release / acquire pair is the default.
@@ -1109,6 +1143,17 @@ static bool overlap_residuals(const ipm_handle* h) {
 }
 
 static inline bool sp_on(const ipm_handle* h) { return h->spf && !h->spf_off; }
+// Sparse factor: one launch per LEVEL of the panel tree (the kernel boundary is the hand-off, nothing spins) instead of one
+// launch per sweep with flag hand-offs between tasks.  Chosen by IPM_SP_MODE=level, and automatically wherever the handle
+// shares the device -- IPM_FLAG_NO_DEVICE_POLLING (batched mode) or more than one live handle: spinning consumers next to
+// other LPs' kernels are what turned STOCFOR3's 0.10 s into 1.4-1.7 s in a shared run, and the level form measured equal
+// under contention (73-LP suite 3.11-3.15 s vs 3.20-3.32 s).  Same arithmetic, bit-identical results.  Mirrors the `alone`
+// rule of the dense look-ahead (enqueue_factor).
+static inline bool sp_level(const ipm_handle* h) {
+    if (h->sp_serial || h->sp_level_mode < 0) return false;
+    if (h->sp_level_mode > 0 || (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING)) return true;
+    return h->device < MAX_DEVICES && g_live[h->device].load(std::memory_order_acquire) > 1;
+}
 static inline unsigned sp_launch_grid(ipm_handle* h) {
     if (h->sp_serial) { ++h->sp_serial_launches; return 1u; }
     return (unsigned)h->sp_grid;
@@ -1151,9 +1196,9 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
     g.tile_order = h->d_tile_order;
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;
-    g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = (int)h->m; g.done = &h->sc->done;
+    g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = (int)h->m; g.done = h->fdone ? h->fdone : &h->sc->done;
     if (h->form_variant == 0 && h->np <= (1 << 20)) {      // dedicated software-pipelined kernel (adat_syrk_f64.h)
-        HIP_TRY(h, launch_adat_syrk(h->A, h->np, d, h->B, h->mp, (int)h->mp, (int)h->np, (int)h->m, &h->sc->done,
+        HIP_TRY(h, launch_adat_syrk(h->A, h->np, d, h->B, h->mp, (int)h->mp, (int)h->np, (int)h->m, h->fdone ? h->fdone : &h->sc->done,
                                     h->d_tile_order, h->stream, h->slab, 512));
         return IPM_OK;
     }
@@ -1185,7 +1230,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         else { if (h->sp_sc1) SP_LAUNCH_CHOL(SPC_THREADS, true, GRID, RECS, COUNT); else SP_LAUNCH_CHOL(SPC_THREADS, false, GRID, RECS, COUNT); } \
     } while (0)
         const unsigned ep = ++h->sp_epoch;
-        if (h->sp_level_mode && !h->sp_serial) {
+        if (sp_level(h)) {
             // one launch per level of the panel tree, leaves first: the kernel boundary is the hand-off (~5 us against ~8-20 us
             // for a flag hand-off inside one launch), nothing spins, and concurrent handles interleave at launch granularity
             for (size_t l = 0; l + 1 < h->sp_lvlptr.size(); ++l) {
@@ -1200,7 +1245,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }
-    const int* done = &h->sc->done;
+    const int* done = h->fdone ? h->fdone : &h->sc->done;
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
     hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
@@ -1490,7 +1535,7 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
     } while (0)
         unsigned ep = ++h->sp_epoch;
         const size_t nlev = h->sp_lvlptr.size() > 0 ? h->sp_lvlptr.size() - 1 : 0;
-        if (h->sp_level_mode && !h->sp_serial) {
+        if (sp_level(h)) {
             for (size_t l = 0; l < nlev; ++l) {
                 const int cnt = h->sp_lvlptr[l + 1] - h->sp_lvlptr[l];
                 SP_SWEEP(SP_LAUNCH_FWD, (unsigned)std::min(cnt, h->sp_grid), h->sp_rec_level + h->sp_lvlptr[l], cnt);
@@ -1592,6 +1637,11 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         VecArgs a = vec_args(h);
         hipLaunchKernelGGL(scaling_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
         if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+        // the stop test of THIS iterate runs on the residual stream while the factorization is in flight: formation and
+        // factorization test the latch scaling_kernel took (Scalars::done_f), so they either run whole or not at all and
+        // after a converged solve B / invD hold the complete factor of the final iterate (ipm_get_factor, pivots_fixed)
+        struct Latch { ipm_handle* h; ~Latch() { h->fdone = nullptr; } } latch{h};
+        h->fdone = &h->sc->done_f;
         if ((rc = enqueue_form(h, h->d))) return rc;
         if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
         // start late in the chain-bound tail: the three passes need ~0.2 ms, six steps of the chain.  Measured at 32 blocks
@@ -1600,6 +1650,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
         const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
         if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
+        h->fdone = nullptr;
         if (gstep >= 0) {
             // the last group's inverse (nine dependent launches, ~80 us) goes to the residual stream as well: the forward
             // sweep of the predictor over the earlier groups runs beside it and only its last step waits
@@ -1684,7 +1735,7 @@ static int enqueue_snapshot(ipm_handle* h, int restore) {
     return IPM_OK;
 }
 // can the next factorization time out at all?  (mirrors the `fs` rule of enqueue_factor)
-static bool may_poll(const ipm_handle* h) { return (h->spf && !h->sp_serial && !h->sp_level_mode) || h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
+static bool may_poll(const ipm_handle* h) { return (h->spf && !h->sp_serial && !sp_level(h)) || h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr && h->flag_sync != 0; }
 
 static void fill_stats(ipm_handle* h, ipm_stats* st, double ms) {
     if (!st) return;

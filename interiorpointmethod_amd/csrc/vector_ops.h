@@ -33,7 +33,10 @@ struct Scalars {
     double maxdiag;
     double e1, e2, e3, eta;
     double obj_last_finite;      // last finite c^T x seen by the stop test (main.py:1227-1233 returns it on NaN)
-    int done, status, k, max_iter, fixed, force, fixed_first, pad1;   // fixed_first: guarded pivots of the first factorization
+    int done, status, k, max_iter, fixed, force, fixed_first;   // fixed_first: guarded pivots of the first factorization
+    int done_f;                  // `done` as it stood when the iteration's formation began (scaling_kernel): what the formation and
+                                 // factorization kernels of the overlapped path test, so that a stop test that flips `done` while
+                                 // they are in flight (it runs on the residual stream) never leaves B half factored
 };
 
 // per-iteration record (include/ipm_hip.h: ipm_iter_record), written by update_kernel into a ring
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(VBLK) void prepare_kernel(VecArgs a) {
 // d = x / s only (main.py:223): what the formation of A D^2 A^T needs; the full prepare_kernel follows on the residual
 // stream while the factorization runs (ipm_api.hip, enqueue_iteration)
 __global__ __launch_bounds__(VBLK) void scaling_kernel(VecArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.sc->done_f = a.sc->done;      // latch for this iteration's factorization
     if (a.sc->done) return;
     const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
     for (int j = gid; j < a.n; j += gsz) a.d[j] = a.x[j] / a.s[j];

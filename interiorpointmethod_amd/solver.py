@@ -89,6 +89,8 @@ def sparse_factor_order(A):
 
 
 SPARSE_FACTOR_MIN_ROWS = 600          # below five 128-row blocks the dense chain is shorter than one tree sweep set
+FUSED_SMALL_MAX_ROWS = 128            # sparse handles up to this many rows run the fused single-workgroup kernel (small_lp.h)
+ORDER_INFO_CACHE = {}                 # id(A) -> ipm_order_rows info of the LPs path_flops put on the sparse factor (bench.py)
 
 
 def prefer_sparse_factor(m, info, dense_blocks):
@@ -121,10 +123,11 @@ def path_flops(A, factor=None):
     dense-tile path factor_flops(A) and 4 m^2.  bench.py's roofline denominator for the Netlib runs."""
     m = A.shape[0]
     factor = factor or os.environ.get("IPM_FACTOR", "auto")
-    if _sp is not None and _sp.issparse(A) and factor != "dense" and \
+    if _sp is not None and _sp.issparse(A) and factor != "dense" and m > FUSED_SMALL_MAX_ROWS and \
             (factor == "sparse" or (m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(_sp.csc_matrix(A)))):
         perm, info = sparse_factor_order(A)
         if perm is not None and (factor == "sparse" or prefer_sparse_factor(m, info, (m + 127) // 128)):
+            ORDER_INFO_CACHE[id(A)] = info
             return "sparse", float(info["flops"]), 4.0 * info["nnz_factor"]
     return "dense", factor_flops(A), 4.0 * m * m
 
@@ -258,6 +261,10 @@ class IpmSolver:
             self._check(lib.ipm_set_A_csc(h, indptr.ctypes.data_as(C.POINTER(C.c_int32)),
                                           indices.ctypes.data_as(C.POINTER(C.c_int32)), _dptr(data),
                                           int(data.shape[0])))
+            if self.factor == "sparse" and self.schedule()["fused_small"]:
+                # m <= 128: the library serves the LP with the fused single-workgroup kernel and builds no sparse factor
+                # (ipm_set_A_csc); report the path the handle really takes (the row order stays: it is harmless)
+                self.factor, self.order_info = "dense", None
         else:
             self._check(lib.ipm_set_A_dense(h, C.c_void_p(A.ctypes.data), self.n, 0))
         self._check(lib.ipm_set_bc(h, _dptr(b), _dptr(c)))
@@ -476,6 +483,12 @@ def solve_with_info(A, b, c, tol=1e-8, max_iter=5000, y0=1.0, device=0, tol_gap=
         if history:
             info["history"] = sv.history()
         fac = sv.factor
+        # the library's hidden recoveries (batch.RECORD_FIELDS): polls that timed out and were rolled back and repeated,
+        # and sparse-factor sweeps that ran as one workgroup after such a time-out
+        info["timeouts_recovered"] = sv.schedule()["timeouts_recovered"]
+        fi = sv.factor_info()
+        info["serial_launches"] = fi["serial_launches"] if fi else 0
+        info["factor_path"] = fac
     t3 = _time.perf_counter()
     # host-side phases of the call (seconds): handle creation + upload + symbolic analysis, the solve, read-back + destroy
     info["setup_seconds"], info["solve_seconds"], info["teardown_seconds"] = t1 - t0, t2 - t1, t3 - t2

@@ -43,3 +43,20 @@ def factor_solve(A, d, rhs, eps=1e-30, big=1e64, shift_rel=0.0, wcap=32, lds=768
         raise RuntimeError("spchol_oracle failed with code %d" % rc)
     keys = ("panels", "height", "widest_front", "factor_entries", "update_entries", "flops", "fan_in_nodes", "max_children")
     return dict(perm=perm.astype(np.int64), L=L, z=z, fixed=nf.value, stats=dict(zip(keys, st)))
+
+
+def symbolic_structures(A, wcap=32, lds=7680):
+    """(perm, etree parent, entries per column of L) as csrc/sparse_symbolic.h computes them (amalgamation off), for
+    the independent NumPy check of tests/test_sparse_symbolic.py."""
+    A = sp.csc_matrix(A, dtype=np.float64)
+    A.sort_indices()
+    m, n = A.shape
+    pi = C.POINTER(C.c_int32)
+    perm, parent, cnt = (np.zeros(m, dtype=np.int32) for _ in range(3))
+    ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ii = np.ascontiguousarray(A.indices, dtype=np.int32)
+    rc = load().spsym_structures(m, n, ip.ctypes.data_as(pi), ii.ctypes.data_as(pi), wcap, lds, perm.ctypes.data_as(pi),
+                                 parent.ctypes.data_as(pi), cnt.ctypes.data_as(pi))
+    if rc:
+        raise RuntimeError("spsym_structures failed with code %d" % rc)
+    return perm.astype(np.int64), parent.astype(np.int64), cnt.astype(np.int64)

@@ -167,4 +167,27 @@ int spchol_oracle(int m, int n, const int* cp, const int* ri, const double* cv, 
     return 0;
 }
 
+// Symbolic structures of the PRODUCT's analysis (csrc/sparse_symbolic.h) laid open for an independent check
+// (tests/test_sparse_symbolic.py compares them with a 20-line NumPy restatement that shares no code with that header):
+// the fill-reducing order perm[m] (new -> old), the elimination-tree parent array of the permuted pattern, and the
+// entries of every column of L (diagonal included) as the panel structures of analyse() imply them with amalgamation
+// switched off (relax = 0: fundamental supernodes, no explicit zeros).  Returns 0, or a positive code.
+int spsym_structures(int m, int n, const int* cp, const int* ri, int wcap, int lds, int* perm, int* parent, int* colcount) {
+    std::vector<int> pv, par;
+    OrderInfo oi;
+    if (order_rows(m, n, cp, ri, pv, oi)) return 1;
+    Pattern P, Q;
+    if (!normal_pattern(m, n, cp, ri, (int64_t)1.5e8, P)) return 2;
+    permute(P, pv, Q);
+    etree(Q, par);
+    Supernodes S;
+    if (analyse(Q, wcap, lds, S, (int64_t)3e8, 0.0)) return 3;
+    for (int i = 0; i < m; ++i) { perm[i] = pv[i]; parent[i] = par[i]; colcount[i] = -1; }
+    for (int J = 0; J < S.nsn; ++J) {
+        const int r = (int)(S.rowptr[(size_t)J + 1] - S.rowptr[J]), w = S.w[J];
+        for (int b = 0; b < w; ++b) colcount[S.c0[J] + b] = r - b;
+    }
+    return 0;
+}
+
 }  // extern "C"

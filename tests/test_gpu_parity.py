@@ -521,6 +521,37 @@ def test_new_interior_sparse_general_form(golden_dir, name):
         assert name in ("KB2", "SCORPION")
 
 
+# General-form files that do NOT converge from the reference's start x = s = y = 1 on this path, with the status they end
+# in (2 = iteration cap of the driver, 999; 3 = NaN).  Their trajectories are chaotic, so which of them
+# converge depends on summation orders: STANDATA converged in 190 iterations until round 2 regrouped the triangular solves
+# of small handles.  They stay listed so that the NEXT change of a summation order shows up here as a diff instead of
+# being curated out of the parity list above.
+GENERAL_EXPECTED_UNCONVERGED = {"STANDATA": 3, "SHELL": None, "SCAGR25": None}
+
+
+@pytest.mark.parametrize("name", sorted(GENERAL_EXPECTED_UNCONVERGED))
+def test_general_form_unconverged_files_keep_their_status(golden_dir, name):
+    from interiorpointmethod_amd import general_form as G
+    z = np.load(os.path.join(golden_dir, "general", name + ".npz"))
+
+    def mat(prefix):
+        if prefix + "_none" in z.files:
+            return None
+        return sparse.csc_matrix((z[prefix + "_data"], z[prefix + "_indices"], z[prefix + "_indptr"]),
+                                 shape=tuple(int(v) for v in z[prefix + "_shape"]))
+    kw = dict(c=z["c"], Aineq=mat("Aineq"), bineq=z["bineq"] if "bineq" in z.files else None, Aeq=mat("Aeq"),
+              beq=z["beq"] if "beq" in z.files else None, lb=z["lb"], ub=z["ub"], tol=1e-8, return_info=True)
+    obj, info = G.new_interior_sparse(**kw)
+    assert info["status"] in (2, 3)
+    want = GENERAL_EXPECTED_UNCONVERGED[name]
+    assert want is None or info["status"] == want, (name, info["status"], info["iterations"])
+    obj2, info2 = G.new_interior_sparse(**kw)                     # chaotic, but deterministic
+    assert info2["status"] == info["status"] and info2["iterations"] == info["iterations"]
+    _, info_m = G.new_interior_sparse(start="mehrotra", **kw)      # and solvable: from the optional robust start
+    opt = float(z["netlib_optimum"])
+    assert info_m["status"] == 1 and abs(info_m["objective"] - opt) <= 1e-5 * max(1.0, abs(opt))
+
+
 def test_two_level_blocking_option(monkeypatch):
     """Grouped Cholesky steps with K = 128*gs trailing updates (default: groups of 2 from 48 blocks on; forced here at 9
     and 16 blocks with groups of 2, 3 and 4, 3 not dividing the block count): same factor as the one-level schedule up
@@ -827,10 +858,12 @@ def test_dense_16384x32768_config5(monkeypatch):
 
 
 def test_netlib_suite_batched_config4(golden_dir):
-    """BASELINE.json configs[3]: ALL 73 valid benchmarks/ LPs through batch.run_batch with two LPs in flight (the
-    driver loop of script.py:147-173, tol=1e-8, cap 300).  Every record is a solver status (converged / cap / NaN:
-    the reference itself converges on 26 only) -- no library error -- the 26 parity LPs reproduce the
-    reference's objectives (e2e_*.npz) to 1e-6 relative, and the table equals the one-at-a-time run."""
+    """BASELINE.json configs[3]: ALL 73 valid benchmarks/ LPs through batch.run_batch with EIGHT LPs in flight -- what
+    bench.py runs -- (the driver loop of script.py:147-173, tol=1e-8, cap 300).  Every record is a solver status
+    (converged / cap / NaN: the reference itself converges on 26 only) -- no library error -- the 26
+    parity LPs reproduce the reference's objectives (e2e_*.npz) to 1e-6 relative, the table equals the one-at-a-time
+    run, and the library's hidden recoveries stayed hidden because there were none: no hand-off poll timed out and was
+    rolled back (timeouts_recovered), no sparse-factor sweep ran as one workgroup (serial_launches), in either run."""
     import glob
     from interiorpointmethod_amd import batch
     names, probs = [], []
@@ -839,9 +872,13 @@ def test_netlib_suite_batched_config4(golden_dir):
         if valid:
             names.append(os.path.basename(f)[:-4]); probs.append((A, b, c))
     assert len(names) == 73
-    par, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=2)
+    par, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=8)
     assert np.array_equal(par[:, 0], np.arange(73))
     assert set(par[:, 1].tolist()) <= {1.0, 2.0, 3.0}, [(names[int(r[0])], r[1]) for r in par if r[1] not in (1, 2, 3)]
+    F = batch.RECORD_FIELDS
+    assert not par[:, F.index("timeouts_recovered")].any(), [names[int(r[0])] for r in par if r[F.index("timeouts_recovered")]]
+    assert not par[:, F.index("serial_launches")].any(), [names[int(r[0])] for r in par if r[F.index("serial_launches")]]
+    assert np.all(par[:, F.index("solve_seconds")] > 0) and np.all(par[:, F.index("setup_seconds")] > 0)
     conv = {names[int(r[0])] for r in par if r[1] == 1.0}
     assert set(PARITY_FAST) <= conv and {"QAP8", "QAP12", "QAP15"} <= conv
     for r in par:
@@ -850,6 +887,7 @@ def test_netlib_suite_batched_config4(golden_dir):
             ref = float(np.load(os.path.join(golden_dir, "e2e_%s.npz" % nm))["objective"])
             assert abs(r[3] - ref) <= 1e-6 * max(1.0, abs(ref)), (nm, r[3], ref)
     seq, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=1)
+    assert not seq[:, F.index("timeouts_recovered")].any() and not seq[:, F.index("serial_launches")].any()
     same = (seq[:, 3] == par[:, 3]) | (np.isnan(seq[:, 3]) & np.isnan(par[:, 3]))
     assert np.array_equal(seq[:, 1:3], par[:, 1:3]) and np.all(same)
     assert batch.summarize(par)["total_iterations"] == batch.summarize(seq)["total_iterations"]
@@ -887,6 +925,69 @@ def test_batch_two_at_a_time_same_records(golden_dir):
     assert np.array_equal(seq[:, 0], np.arange(len(names))) and np.array_equal(par[:, 0], seq[:, 0])
     assert np.all(seq[:, 1] == 1.0)
     assert np.array_equal(par[:, 1:4], seq[:, 1:4])            # status, iterations, objective
+
+
+def test_rccl_branch_with_one_rank(golden_dir, tmp_path):
+    """The RCCL code path on the one GPU a test box has: a process group of ONE rank over backend "nccl" (= RCCL on ROCm),
+    (i) batch.gather_records / batch._gather_sparse pushed through dist.all_gather with DEVICE tensors of the record
+    shape (float64 (cap, NF)), (ii) a batched solve with the self-scheduling counter on a TCPStore and the records
+    gathered on the device, (iii) bench.py --workload netlib under torch.distributed.run --nproc-per-node 1 with
+    IPM_BENCH_FORCE_DIST=1.  Proves the library loads, the gathers work and the store path is sound before a driver
+    hands the job eight GPUs; own processes, so the test session's torch state is untouched."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    code = r'''
+import os, numpy as np, torch, torch.distributed as dist
+from interiorpointmethod_amd import batch
+from interiorpointmethod_amd.matio import load_npz_problem
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(0)
+local = np.column_stack([np.arange(5.0)[::-1], rng.standard_normal((5, batch.NF - 1))])
+out = batch.gather_records(local, [5], dist=dist, device=dev)              # padded (cap, NF) float64 through all_gather
+assert np.array_equal(out, local[::-1])
+tab = np.full((7, batch.NF), -1.0); tab[[1, 4]] = rng.standard_normal((2, batch.NF)); tab[[1, 4], 0] = [1, 4]
+got = batch._gather_sparse(tab, dist, device=dev)
+assert np.array_equal(got, tab)
+store = batch.make_store(0, 1, host="127.0.0.1", port=int(os.environ["MASTER_PORT"]) + 1)
+names = ["AFIRO", "SC50A", "BANDM", "SCSD6", "STOCFOR2"]
+probs = [load_npz_problem(os.path.join(os.environ["GOLDEN"], "netlib", nm + ".npz"))[:3] for nm in names]
+for sched in ("dynamic", "static"):
+    rec, _ = batch.run_batch(probs, device=0, dist=dist, store=store, schedule=sched, workers=2, gather_device=dev,
+                             collective_at_world_one=True, tol=1e-8, max_iter=300)
+    assert np.array_equal(rec[:, 0], np.arange(5)) and np.all(rec[:, 1] == 1.0), rec[:, :3]
+ref, _ = batch.run_batch(probs, device=0, tol=1e-8, max_iter=300)
+assert np.array_equal(ref[:, 1:4], rec[:, 1:4])
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(env, GOLDEN=golden_dir))
+    assert out.returncode == 0 and "RCCL_ONE_RANK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port2 = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port2), os.path.join(root, "bench.py"), "--workload", "netlib", "--netlib-set", "parity",
+           "--max-m", "1500", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, IPM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "backend nccl" in line["config"]["workload"] and "TCPStore" in line["config"]["workload"]
+    assert line["summary"]["converged"] == line["summary"]["n"] >= 20 and line["summary"]["errors"] == 0
+    assert line["summary"]["timeouts_recovered"] == 0 and line["summary"]["serial_launches"] == 0
 
 
 def test_plain_c_driver():

@@ -53,10 +53,17 @@ def test_synthetic_workload_pins():
 
 
 def test_record_layout_and_summary():
-    assert batch.RECORD_FIELDS[:4] == ("id", "status", "iterations", "objective") and batch.NF == 9
-    rec = np.array([[0, 1, 10, 1.0, 0, 0, 0, 0.1, 2], [1, 3, 5, np.nan, 0, 0, 0, 0.2, 0], [2, -6, 0, np.nan, 0, 0, 0, 0.0, 0]])
+    assert batch.RECORD_FIELDS[:4] == ("id", "status", "iterations", "objective") and batch.NF == 14
+    assert batch.RECORD_FIELDS[9:] == ("timeouts_recovered", "serial_launches", "setup_seconds", "solve_seconds",
+                                       "teardown_seconds")
+    rec = np.array([[0, 1, 10, 1.0, 0, 0, 0, 0.1, 2, 1, 3, 0.01, 0.05, 0.02], [1, 3, 5, np.nan, 0, 0, 0, 0.2, 0, 0, 0, 0, 0, 0],
+                    [2, -6, 0, np.nan, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0]])
     s = batch.summarize(rec)
     assert (s["converged"], s["nan"], s["invalid"], s["total_iterations"], s["pivots_fixed"]) == (1, 1, 1, 15, 2)
+    assert (s["timeouts_recovered"], s["serial_launches"]) == (1, 3) and abs(s["device_solve_seconds_sum"] - 0.05) < 1e-15
+    # a custom solve_fn that reports only the nine basic statistics still yields a full-width record (zeros)
+    row = batch._row(4, dict(status=1, iterations=3, objective=2.0, rp=0, rd=0, gap=0, seconds=0.1, pivots_fixed=0))
+    assert len(row) == batch.NF and row[9:] == [0.0] * 5
 
 
 def test_envelope_row_order_recovers_a_staircase():

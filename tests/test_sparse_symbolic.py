@@ -161,3 +161,93 @@ def test_multifrontal_oracle_solves_the_normal_equations(oracle, name):
     res = np.linalg.norm(B @ out["z"] + shift * out["z"] - rhs) / np.linalg.norm(rhs)
     assert out["fixed"] == 0 and res <= 1e-6, (name, out["fixed"], res, out["stats"])      # (a wrong index gives O(1))
     assert out["stats"]["max_children"] <= 12
+
+
+def _numpy_etree_and_counts(P):
+    """Independent restatement (shares no code with csrc/sparse_symbolic.h): Liu's elimination tree by ancestor path
+    compression, and the entries of every column of L by explicit symbolic elimination (the structure of column k is its
+    own below-diagonal pattern united with the structures of the columns whose first below-diagonal entry is k)."""
+    P = sp.csc_matrix(P)
+    m = P.shape[0]
+    parent = -np.ones(m, dtype=np.int64)
+    anc = -np.ones(m, dtype=np.int64)
+    for i in range(m):
+        for k in P.indices[P.indptr[i]:P.indptr[i + 1]]:
+            while k != -1 and k < i:
+                nxt = anc[k]
+                anc[k] = i
+                if nxt == -1:
+                    parent[k] = i
+                k = nxt
+    below = [set(int(r) for r in P.indices[P.indptr[k]:P.indptr[k + 1]] if r > k) for k in range(m)]
+    counts = np.zeros(m, dtype=np.int64)
+    for k in range(m):
+        counts[k] = len(below[k]) + 1
+        if below[k]:
+            p = min(below[k])
+            below[p] |= below[k] - {p}
+        below[k] = None
+    return parent, counts
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC205", "BANDM", "SCTAP1"])
+def test_etree_and_column_counts_against_an_independent_numpy_restatement(oracle, name):
+    """The product's symbolic analysis (order -> elimination tree -> column structures by child merging -> panels) against
+    a NumPy restatement that shares nothing with csrc/sparse_symbolic.h: same elimination-tree parent array, same number
+    of entries in every column of L, the order is a postorder of that tree (parent after child, subtrees contiguous), and
+    the first below-diagonal entry of a column is its parent."""
+    A, b, c = _lp(name)
+    perm, parent, cnt = oracle.symbolic_structures(A)
+    m = A.shape[0]
+    assert sorted(perm.tolist()) == list(range(m))
+    Ab = A.copy()
+    Ab.data[:] = 1.0
+    P = sp.csr_matrix(Ab @ Ab.T)[perm][:, perm]
+    ref_parent, ref_cnt = _numpy_etree_and_counts(P)
+    assert np.array_equal(parent, ref_parent)
+    assert np.array_equal(cnt, ref_cnt)
+    assert int(cnt.sum()) == S.sparse_factor_order(A)[1]["nnz_factor"]
+    # postorder: every vertex precedes its parent and each subtree is one contiguous index range ending at its root
+    size = np.ones(m, dtype=np.int64)
+    for k in range(m):
+        if parent[k] >= 0:
+            assert parent[k] > k
+            size[parent[k]] += size[k]
+    first = np.arange(m) - size + 1
+    for k in range(m):
+        if parent[k] >= 0:
+            assert first[parent[k]] <= first[k]
+
+
+ASAN_SET = ["AFIRO", "SC105", "SC205", "BANDM", "E226", "SCTAP1", "SHELL", "25FV47", "CZPROB", "STOCFOR2"]
+
+
+def test_sparse_symbolic_and_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/sparse_symbolic.h (host code of the PRODUCT: ordering, elimination tree, amalgamation, panels, fan-in nodes)
+    together with the C++ oracle, compiled with -fsanitize=address,undefined on the CPU (GPU sanitizers are not
+    available on the pool) and run over ten Netlib structures at two panel budgets (the GPU's 32 x 7680 and a tiny one
+    that forces panel splits and fan-in nodes): no report, exit status 0."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmp_path, "asan_sparse_driver")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I" + os.path.join(root, "interiorpointmethod_amd", "csrc"), "-I" + os.path.join(root, "oracle"),
+           os.path.join(root, "tests", "asan_sparse_driver.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    for name in ASAN_SET:
+        A, b, c = _lp(name)
+        A.sort_indices()
+        f = os.path.join(tmp_path, name + ".bin")
+        with open(f, "wb") as fh:
+            np.array([A.shape[0], A.shape[1], A.nnz], dtype=np.int32).tofile(fh)
+            A.indptr.astype(np.int32).tofile(fh)
+            A.indices.astype(np.int32).tofile(fh)
+            A.data.astype(np.float64).tofile(fh)
+        out = subprocess.run([exe, f], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+        assert out.returncode == 0, (name, out.stdout[-2000:], out.stderr[-4000:])
+        assert "ok" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr

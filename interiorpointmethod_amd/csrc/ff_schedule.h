@@ -1,0 +1,226 @@
+// ff_schedule.h -- host side of the fused formation + factorization (form_factor.h): the ORDERED WORK LIST the
+// persistent workers draw from.  Plain C++ (no HIP): built into libipm_hip.so, and checked on the CPU through
+// ipm_debug_ff_schedule (tests/test_ff_schedule.py).
+//
+// What is being scheduled (dense handles, 128 x 128 tiles (i, c), i >= c, of B = A D^2 A^T and of its Cholesky factor;
+// replaces main.py:224 + the factorization inside main.py:180/:226 of the reference, fused):
+//   F(i,c,q)          one of Q K-chunks of the formation of tile (i,c): a raw partial tile into slab (tile, q)
+//   T(i,c,[j0,j1))    tile (i,c) -= sum_{j0<=j<j1} L(i,j) L(c,j)^T, optionally + the Q formation slabs (ADD_BASE, once per
+//                     tile, any time after its F chunks), optionally followed by the panel solve L(i,c) = tile inv(L(c,c))^T
+//                     (PANEL, once, after everything else of the tile and after the diagonal block c is factored)
+// and, outside the list, the PIVOT CHAIN on its own stream and its own CUs: potrf(k) of diagonal block k, the panel solve
+// of tile (k+1,k) and the update of tile (k+1,k+1) by column k (the existing kernels of potrf_f64.h / gemm_nt_f64.h).
+// The chain's tiles get everything else from the workers: tile (k+1,k) columns [0,k), tile (k,k) columns [0,k-1).
+//
+// Why an ordered list and one ticket counter: a worker takes the next item of the list, waits (bounded spin) for what the
+// item needs, runs it.  Everything an item needs is produced by items EARLIER in the list (or by the chain, which itself
+// only needs earlier items), and earlier items are held by workgroups that are running, so the launch cannot deadlock
+// whatever the residency or timing; a bad order only costs waiting.  The order is the start order of a discrete-event
+// simulation of the machine (workers, chain, durations measured on MI355X) under a priority rule:
+//   (0) tiles in the chain's window (their column is at most 2 steps ahead) as soon as anything can be applied to them,
+//   (1) final batches (everything up to the tile's last column is available),
+//   (2) batches of >= FF_BATCH columns for tiles further away (few read-modify-write passes per tile),
+//   (3) the next formation chunk (column-major, so that columns become complete in the order the chain needs them),
+//   (4) anything left once the formation is exhausted.
+// The list is a pure function of (nblk, Q, workers): the arithmetic order of every tile is fixed, results are bitwise
+// reproducible.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <limits>
+#include <queue>
+#include <set>
+#include <vector>
+
+namespace ipm {
+
+struct FFItem {
+    unsigned char type;        // FF_F / FF_T
+    unsigned char i, c;        // tile
+    unsigned char q;           // F: K-chunk
+    unsigned char j0, j1;      // T: column range of L applied
+    unsigned char flags;       // T: FF_INIT | FF_ADD_BASE | FF_PANEL | FF_SIG_DIAG0
+    unsigned char seq;         // T: 1-based sequence number among the tile's T items (tprog hand-off)
+};
+enum { FF_F = 0, FF_T = 1 };
+enum { FF_INIT = 1, FF_ADD_BASE = 2, FF_PANEL = 4, FF_SIG_DIAG0 = 8 };
+constexpr int FF_BATCH = 4;            // columns of L per deferred batch (K = 512)
+constexpr int FF_WINDOW = 2;           // chain look-ahead: columns within this many steps are served at once
+constexpr int FF_MAX_NBLK = 96;
+
+inline int ff_tile(int i, int c) { return i * (i + 1) / 2 + c; }
+
+struct FFModel {                       // durations in microseconds (MI355X, one 512-thread workgroup per CU)
+    double stage = 3.5;                // one BK = 32 stage of a 128 x 128 tile
+    double f_overhead = 6.0;           // F chunk: prologue + slab store + release
+    double t_overhead = 7.0;           // T item: wait + acquire + tile load / store + release
+    double t_base = 2.0;               // reading Q slabs
+    double t_panel = 16.0;             // second product with inv(L_cc) (4 stages + staging through LDS)
+    double potrf = 38.0, crit_panel = 8.0, crit_update = 6.0, boundary = 3.0;
+    int f_stages = 64;                 // stages per F chunk (set by the caller: K / 32 / Q)
+};
+
+struct FFSchedule {
+    std::vector<FFItem> items;
+    std::vector<int> tile_items;       // [ntile] T items per tile (what the chain waits for on its tiles)
+    double makespan_us = 0.0;          // simulated end of the factorization
+    double form_end_us = 0.0;          // simulated end of the last formation chunk
+};
+
+// columns of L the WORKERS apply to tile (i,c): the chain applies column c-1 to its diagonal tile itself
+inline int ff_limit(int i, int c) { return (i == c) ? (c > 0 ? c - 1 : 0) : c; }
+inline bool ff_needs_panel(int i, int c) { return i > c + 1; }
+
+inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedule& out) {
+    const double INF = std::numeric_limits<double>::infinity();
+    const int ntile = nblk * (nblk + 1) / 2;
+    struct Tile {
+        int i, c, limit; bool panel;
+        int f_sched = 0; double f_time = 0.0;          // F chunks scheduled, latest finish
+        bool base_in = false, paneled = false;
+        int applied = 0, nitems = 0;
+        double ready = 0.0;                            // finish time of the last T item scheduled on the tile
+        bool complete() const { return base_in && applied == limit && (!panel || paneled); }
+    };
+    std::vector<Tile> T((size_t)ntile);
+    for (int i = 0; i < nblk; ++i)
+        for (int c = 0; c <= i; ++c) { Tile& t = T[(size_t)ff_tile(i, c)]; t.i = i; t.c = c; t.limit = ff_limit(i, c); t.panel = ff_needs_panel(i, c); }
+    // rowfin[r][j]: time tile (r, j) became L (j < r)
+    std::vector<std::vector<double>> rowfin((size_t)nblk);
+    for (int r = 0; r < nblk; ++r) rowfin[(size_t)r].assign((size_t)r + 1, INF);
+    std::vector<int> rf((size_t)nblk, 0);              // leading tiles of row r final at the current time
+    std::vector<double> potrf_done((size_t)nblk, INF), potrf_start((size_t)nblk, INF);
+    // formation order: column-major, chunk-major inside a column (concurrent items share the column's Q panel chunk)
+    std::vector<FFItem> forder;
+    for (int c = 0; c < nblk; ++c)
+        for (int q = 0; q < Q; ++q)
+            for (int i = c; i < nblk; ++i) { FFItem it{}; it.type = FF_F; it.i = (unsigned char)i; it.c = (unsigned char)c; it.q = (unsigned char)q; forder.push_back(it); }
+    size_t fnext = 0;
+    std::multiset<double> events;                       // future times at which the state changes
+    // ---- chain state machine
+    int ck = 0, cphase = 0;                             // step, 0: potrf pending, 1: crit panel pending, 2: crit update pending
+    double chain_free = 0.0, diag_ready = INF, panel_end = 0.0;
+    auto tile_done_time = [&](int i, int c) -> double { const Tile& t = T[(size_t)ff_tile(i, c)]; return t.complete() ? t.ready : INF; };
+    auto advance_chain = [&]() {
+        for (;;) {
+            if (ck >= nblk) return;
+            if (cphase == 0) {
+                if (ck == 0) diag_ready = tile_done_time(0, 0);
+                if (diag_ready == INF) return;
+                potrf_start[(size_t)ck] = std::max(chain_free + M.boundary, diag_ready);
+                potrf_done[(size_t)ck] = potrf_start[(size_t)ck] + M.potrf;
+                events.insert(potrf_start[(size_t)ck]); events.insert(potrf_done[(size_t)ck]);
+                chain_free = potrf_done[(size_t)ck];
+                if (ck + 1 >= nblk) { out.makespan_us = chain_free; ck = nblk; return; }
+                cphase = 1;
+            }
+            if (cphase == 1) {
+                const double tw = tile_done_time(ck + 1, ck);
+                if (tw == INF) return;
+                panel_end = std::max(chain_free + M.boundary, tw) + M.crit_panel;
+                rowfin[(size_t)ck + 1][(size_t)ck] = panel_end;
+                events.insert(panel_end);
+                chain_free = panel_end;
+                cphase = 2;
+            }
+            if (cphase == 2) {
+                const double tw = tile_done_time(ck + 1, ck + 1);
+                if (tw == INF) return;
+                diag_ready = std::max(chain_free + M.boundary, tw) + M.crit_update;
+                events.insert(diag_ready);
+                chain_free = diag_ready;
+                ++ck; cphase = 0;
+            }
+        }
+    };
+    typedef std::pair<double, int> Ev;                  // (free time, worker)
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> free_at;
+    for (int w = 0; w < W; ++w) free_at.push(Ev(0.0, w));
+    out.items.clear();
+    size_t remaining = (size_t)ntile;                   // tiles not complete
+    int guard = 0;
+    while (!free_at.empty() && remaining > 0) {
+        const Ev ev = free_at.top(); free_at.pop();
+        const double t = ev.first;
+        advance_chain();
+        for (int r = 0; r < nblk; ++r) while (rf[(size_t)r] < r && rowfin[(size_t)r][(size_t)rf[(size_t)r]] <= t) ++rf[(size_t)r];
+        int kc = 0;                                     // chain position: diagonal blocks whose factorization has begun
+        while (kc < nblk && potrf_start[(size_t)kc] <= t) ++kc;
+        // ---- candidates
+        int best = -1, best_class = 99;
+        for (int id = 0; id < ntile; ++id) {
+            const Tile& x = T[(size_t)id];
+            if (x.complete() || x.ready > t) continue;             // done, or an item of the tile is in flight
+            const bool fc = x.f_sched == Q && x.f_time <= t;
+            const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
+            const int pend = a - x.applied;
+            const bool can_base = fc && !x.base_in;
+            const bool base_ok = x.base_in || can_base;
+            const bool panel_ready = x.panel && base_ok && a == x.limit && potrf_done[(size_t)x.c] <= t + 8.0;
+            const bool panel_only = panel_ready && x.base_in && pend == 0;
+            if (!(pend > 0 || can_base || panel_only)) continue;
+            int cls;
+            if (x.c <= kc + FF_WINDOW) cls = 0;
+            else if (base_ok && a == x.limit) cls = 1;
+            else if (pend >= FF_BATCH) cls = 2;
+            else if (can_base && pend == 0 && x.applied == 0 && fnext < forder.size()) continue;   // nothing but the base yet: wait for columns
+            else cls = 4;
+            if (cls == 4 && fnext < forder.size()) continue;       // small deferred batches only once the formation is exhausted
+            if (cls < best_class) { best_class = cls; best = id; }  // ties: lowest tile id = lowest row, then column... see below
+            else if (cls == best_class && best >= 0) {
+                const Tile& y = T[(size_t)best];
+                if (x.c < y.c || (x.c == y.c && x.i < y.i)) best = id;
+            }
+        }
+        if (best < 0 && fnext < forder.size()) {
+            // ---- a formation chunk
+            const FFItem it = forder[fnext++];
+            Tile& x = T[(size_t)ff_tile(it.i, it.c)];
+            const double fin = t + M.f_overhead + M.stage * M.f_stages;
+            x.f_sched++; x.f_time = std::max(x.f_time, fin);
+            out.form_end_us = std::max(out.form_end_us, fin);
+            events.insert(fin);
+            out.items.push_back(it);
+            free_at.push(Ev(fin, ev.second));
+            continue;
+        }
+        if (best < 0) {
+            // nothing to do right now: sleep until the state changes (at run time: the next ticket's wait)
+            auto nx = events.upper_bound(t);
+            if (nx == events.end()) { if (++guard > 4 * W) break; continue; }       // this worker retires
+            free_at.push(Ev(*nx, ev.second));
+            continue;
+        }
+        // ---- a T item on tile `best`
+        Tile& x = T[(size_t)best];
+        const bool fc = x.f_sched == Q && x.f_time <= t;
+        const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
+        FFItem it{};
+        it.type = FF_T; it.i = (unsigned char)x.i; it.c = (unsigned char)x.c;
+        it.j0 = (unsigned char)x.applied; it.j1 = (unsigned char)a;
+        if (x.nitems == 0) it.flags |= FF_INIT;
+        if (fc && !x.base_in) it.flags |= FF_ADD_BASE;
+        const bool base_after = x.base_in || (it.flags & FF_ADD_BASE);
+        double dur = M.t_overhead + M.stage * 4.0 * (a - x.applied) + ((it.flags & FF_ADD_BASE) ? M.t_base : 0.0);
+        double fin = t + dur;
+        if (x.panel && base_after && a == x.limit && potrf_done[(size_t)x.c] <= t + dur + 8.0) {
+            it.flags |= FF_PANEL;
+            fin = std::max(fin, potrf_done[(size_t)x.c]) + M.t_panel;
+        }
+        if (x.i == 0 && x.c == 0) it.flags |= FF_SIG_DIAG0;
+        x.applied = a; x.base_in = base_after; x.nitems++; x.ready = fin;
+        it.seq = (unsigned char)x.nitems;
+        if (it.flags & FF_PANEL) { x.paneled = true; rowfin[(size_t)x.i][(size_t)x.c] = fin; }
+        if (x.complete()) --remaining;
+        events.insert(fin);
+        out.items.push_back(it);
+        free_at.push(Ev(fin, ev.second));
+    }
+    advance_chain();
+    out.tile_items.assign((size_t)ntile, 0);
+    for (int id = 0; id < ntile; ++id) out.tile_items[(size_t)id] = T[(size_t)id].nitems;
+    if (out.makespan_us == 0.0) out.makespan_us = chain_free;
+}
+
+}  // namespace ipm

@@ -1301,6 +1301,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         pd.inv = h->invD + (int64_t)k * NB * NB;
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
+        pd.wait_on = nullptr; pd.wait_count = 0; pd.signal = nullptr; pd.timeout = nullptr;
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
             hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);

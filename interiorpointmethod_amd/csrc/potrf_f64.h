@@ -44,6 +44,12 @@ struct PotrfDiag {
     int* fixed;                  // device counter of guarded pivots (accumulates)
     const int* done;
     long long* stamps;           // diagnostic build only (STAMP = true): s_memtime per phase and wave
+    // Device-side hand-offs of the fused formation + factorization (form_factor.h), all optional (null / 0):
+    // the launch polls *wait_on >= wait_count from one lane before it reads the block (bounded spin, agent acquire) and
+    // bumps *signal once, behind an agent-scope release, after L_kk and inv(L_kk) are written.
+    const unsigned* wait_on; unsigned wait_count;
+    unsigned* signal;
+    unsigned* timeout;
 };
 
 // sqrt(p) and 1/sqrt(p) from v_rsq_f64 (about 23 good bits) and one Halley step
@@ -373,12 +379,32 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
 
 template <bool STAMP>
 __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
-    if (a.done && *a.done) return;
+    if (a.done && *a.done) {
+        if (a.signal && threadIdx.x == 0) __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) double W[NB * WLD];
     __shared__ double dinv_s[NB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.wait_on) {
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.wait_count) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if (spins > (1u << 22) || ((spins & 1023u) == 1u && a.timeout &&
+                                           __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (a.timeout) __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
     const double thresh = a.eps * (*a.maxdiag);
     long long* stamps = a.stamps;
 
@@ -431,6 +457,15 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     write_rows(14, 16, false, NB - 16, NB);           // u = 14, 15 cover rows 112..127
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
+    if (a.signal) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // max of the diagonal of an n x n matrix (single workgroup; n <= a few 10^4)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IPM_ABI_VERSION 3
+#define IPM_ABI_VERSION 4
 
 /* return codes */
 enum {
@@ -190,8 +190,11 @@ int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32
  * out[3] = 1 while cross-stream hand-offs poll device counters (0: stream events), out[4] / out[5] = bulk trailing
  * updates of the last factorization that signalled a counter / recorded an event, out[6] = 1 when the tile envelope
  * of a sparse handle is exploited, out[7] = live handles on this device, out[8] = poll time-outs recovered so far,
- * out[9] = 1 when the fused single-workgroup small-LP path serves this handle. */
-int ipm_get_schedule(ipm_handle* h, int32_t out[10]);
+ * out[9] = 1 when the fused single-workgroup small-LP path serves this handle, out[10] = 1 when the last iteration ran the
+ * FUSED formation + factorization (one persistent launch beside the pivot chain; dense handles of 16 .. 96 blocks that
+ * have the device to themselves), out[11] = 1 while a sparse-factor handle runs one launch per level of its panel tree
+ * (shared device) instead of one launch per sweep.  (ABI 4: twelve words; ABI 3 had ten.) */
+int ipm_get_schedule(ipm_handle* h, int32_t out[12]);
 
 /* Fill-reducing order of the ROWS of an m x n sparse A (CSC, host) for the Cholesky of A D^2 A^T: minimum degree on
  * the pattern of A A^T followed by the elimination-tree postorder.  Pure host code (no device is touched): the
@@ -234,6 +237,13 @@ int ipm_set_profiling(ipm_handle* h, int enable);
 /* Diagnostic builds only (environment IPM_POTRF_STAMPS=1 at ipm_create): s_memtime stamps of the first
  * diagonal-block factorization, 8 waves x 64 slots.  IPM_ERR_STATE otherwise. */
 int ipm_debug_get_stamps(ipm_handle* h, long long* out);
+/* Host only (no device is touched; tests): the ordered work list of the fused formation + factorization for `nblk` 128-row
+ * blocks, `q` formation chunks per tile and `workers` workgroups (csrc/ff_schedule.h).  Up to `capacity` items of 8 bytes
+ * {type, i, c, q, j0, j1, flags, seq} are written to `items`, their number to *count, the number of update items per lower
+ * tile (row-major triangle, nblk (nblk + 1) / 2 entries) to tile_items, and the simulated {end of the factorization, end
+ * of the formation} in microseconds to sim_us. */
+int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, unsigned char* items, int32_t capacity, int32_t* count,
+                          int32_t* tile_items, double sim_us[2]);
 int ipm_get_phase_ms(ipm_handle* h, double out[4]);
 
 #ifdef __cplusplus

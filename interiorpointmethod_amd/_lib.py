@@ -19,7 +19,7 @@ EXPORTS = [
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
     "ipm_iterate", "ipm_solve", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
-    "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps",
+    "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps", "ipm_debug_ff_schedule",
 ]
 
 IPM_OK = 0
@@ -29,7 +29,7 @@ FLAG_NO_AUTO_REGULARIZE = 2     # include/ipm_hip.h: IPM_FLAG_NO_AUTO_REGULARIZE
 FLAG_SINGLE_STREAM = 4          # include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM
 FLAG_SPARSE_FACTOR = 8          # include/ipm_hip.h: IPM_FLAG_SPARSE_FACTOR
 ERR_WORKSPACE = -4
-ABI_VERSION = 3
+ABI_VERSION = 4
 HISTORY_CAPACITY = 1024         # IPM_HISTORY_CAPACITY
 ERR_INVALID_INPUT = -6
 
@@ -131,6 +131,7 @@ def load():
     lib.ipm_set_profiling.argtypes = [vp, C.c_int]
     lib.ipm_get_phase_ms.argtypes = [vp, pd]
     lib.ipm_debug_get_stamps.argtypes = [vp, C.POINTER(C.c_longlong)]
+    lib.ipm_debug_ff_schedule.argtypes = [i32, i32, i32, C.POINTER(C.c_ubyte), i32, C.POINTER(i32), C.POINTER(i32), pd]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("ipm_default_options", "ipm_last_error"):

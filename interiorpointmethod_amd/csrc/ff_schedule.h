@@ -26,6 +26,8 @@
 // reproducible.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <limits>
@@ -38,10 +40,12 @@ namespace ipm {
 struct FFItem {
     unsigned char type;        // FF_F / FF_T
     unsigned char i, c;        // tile
-    unsigned char q;           // F: K-chunk
-    unsigned char j0, j1;      // T: column range of L applied
-    unsigned char flags;       // T: FF_INIT | FF_ADD_BASE | FF_PANEL | FF_SIG_DIAG0
-    unsigned char seq;         // T: 1-based sequence number among the tile's T items (tprog hand-off)
+    unsigned char q;           // F: K-chunk (slab index)
+    union {
+        struct { unsigned char j0, j1, flags, seq; } t;   // T: column range of L applied; FF_INIT | FF_ADD_BASE | FF_PANEL | FF_SIG_DIAG0;
+                                                          //    1-based sequence number among the tile's T items (tprog hand-off)
+        struct { unsigned short s0, s1; } f;              // F: stage range [s0, s1) of the K loop (BK = 32 stages)
+    };
 };
 enum { FF_F = 0, FF_T = 1 };
 enum { FF_INIT = 1, FF_ADD_BASE = 2, FF_PANEL = 4, FF_SIG_DIAG0 = 8 };
@@ -49,7 +53,12 @@ constexpr int FF_BATCH = 4;            // columns of L per deferred batch (K = 5
 constexpr int FF_WINDOW = 2;           // chain look-ahead: columns within this many steps are served at once
 constexpr int FF_MAX_NBLK = 96;
 
-inline int ff_tile(int i, int c) { return i * (i + 1) / 2 + c; }
+#if defined(__HIPCC__)
+#define FF_HD __host__ __device__
+#else
+#define FF_HD
+#endif
+FF_HD inline int ff_tile(int i, int c) { return i * (i + 1) / 2 + c; }
 
 struct FFModel {                       // durations in microseconds (MI355X, one 512-thread workgroup per CU)
     double stage = 3.5;                // one BK = 32 stage of a 128 x 128 tile
@@ -58,7 +67,10 @@ struct FFModel {                       // durations in microseconds (MI355X, one
     double t_base = 2.0;               // reading Q slabs
     double t_panel = 16.0;             // second product with inv(L_cc) (4 stages + staging through LDS)
     double potrf = 38.0, crit_panel = 8.0, crit_update = 6.0, boundary = 3.0;
-    int f_stages = 64;                 // stages per F chunk (set by the caller: K / 32 / Q)
+    int f_stages = 64;                 // stages per F chunk (set by the caller: ceil(K / 32 / Q))
+    int nstages = 256;                 // K / 32 of the formation
+    int stagger = 1;                   // spread the chunk lengths of the first band (see ff_build_schedule)
+    int row_weight = 10, col_weight = 40;   // formation order key = row_weight (i - 1) + col_weight c (see ff_build_schedule)
 };
 
 struct FFSchedule {
@@ -72,9 +84,15 @@ struct FFSchedule {
 inline int ff_limit(int i, int c) { return (i == c) ? (c > 0 ? c - 1 : 0) : c; }
 inline bool ff_needs_panel(int i, int c) { return i > c + 1; }
 
-inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedule& out) {
+inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSchedule& out) {
     const double INF = std::numeric_limits<double>::infinity();
     const int ntile = nblk * (nblk + 1) / 2;
+    const bool trace = getenv("IPM_FF_TRACE") != nullptr;
+    FFModel Mx = M_in;
+    if (const char* e = getenv("IPM_FF_ROW_WEIGHT")) Mx.row_weight = atoi(e);
+    if (const char* e = getenv("IPM_FF_COL_WEIGHT")) Mx.col_weight = atoi(e);
+    if (const char* e = getenv("IPM_FF_STAGGER")) Mx.stagger = atoi(e);
+    const FFModel& M = Mx;
     struct Tile {
         int i, c, limit; bool panel;
         int f_sched = 0; double f_time = 0.0;          // F chunks scheduled, latest finish
@@ -91,11 +109,51 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
     for (int r = 0; r < nblk; ++r) rowfin[(size_t)r].assign((size_t)r + 1, INF);
     std::vector<int> rf((size_t)nblk, 0);              // leading tiles of row r final at the current time
     std::vector<double> potrf_done((size_t)nblk, INF), potrf_start((size_t)nblk, INF);
-    // formation order: column-major, chunk-major inside a column (concurrent items share the column's Q panel chunk)
+    // Formation order = the order in which the factorization needs the tiles.  The pivot chain reaches column c at about
+    // t0 + c * step; row i does not have to be current before the chain gets to step i - 1, and its own pipeline (update +
+    // panel solve of tile (i,c), needing L(i,c-1)) runs at about half a chain step per column, entirely BEHIND the chain if
+    // it starts at t0 + (i - 1) * step / 2.  Tile (i,c) is therefore needed around (i - 1) / 2 + c / 2 chain steps: the
+    // demand grows linearly in time like the formation's supply does (half of the tiles have i + c <= nblk - 1), whereas a
+    // column-major order needs 3/4 of all tiles by half time and leaves the chain waiting for the formation.
+    // Inside a band of W / Q consecutive tiles the chunks go q-major, so the W concurrent items are W / Q tiles x Q chunks.
     std::vector<FFItem> forder;
-    for (int c = 0; c < nblk; ++c)
-        for (int q = 0; q < Q; ++q)
-            for (int i = c; i < nblk; ++i) { FFItem it{}; it.type = FF_F; it.i = (unsigned char)i; it.c = (unsigned char)c; it.q = (unsigned char)q; forder.push_back(it); }
+    {
+        std::vector<std::pair<int, int>> order;             // (key, tile)
+        for (int i = 0; i < nblk; ++i)
+            for (int c = 0; c <= i; ++c) order.emplace_back(M.row_weight * std::max(i - 1, 0) + M.col_weight * c, ff_tile(i, c));
+        std::stable_sort(order.begin(), order.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+            if (a.first != b.first) return a.first < b.first;
+            return T[(size_t)a.second].c < T[(size_t)b.second].c;
+        });
+        // Chunk boundaries in stages.  Uniform, except for the FIRST band (the items every worker starts with): there the
+        // chunk lengths are spread over 0.4 .. 1.6 of the mean, so that the workers do not finish their formation chunks in
+        // lockstep -- with equal chunks all of them are deaf for one whole chunk (hundreds of microseconds) at the same time,
+        // and everything the chain waits for waits with them; staggered, one worker comes free every microsecond or so.
+        const int ns = M.nstages;
+        const size_t band = (size_t)std::max(1, W / std::max(1, Q));
+        for (size_t b0 = 0; b0 < order.size(); b0 += band) {
+            const size_t b1 = std::min(order.size(), b0 + band);
+            std::vector<std::vector<int>> cut(b1 - b0, std::vector<int>((size_t)Q + 1, 0));
+            for (size_t t = b0; t < b1; ++t) {
+                std::vector<double> len((size_t)Q, 1.0);
+                if (b0 == 0 && Q > 1 && M.stagger) {
+                    const double phi = (double)(t - b0) / (double)(b1 - b0) / Q;
+                    for (int q = 0; q < Q; ++q) { double u = (double)q / Q + phi; u -= (double)(int)u; len[(size_t)q] = 0.4 + 1.2 * u; }
+                }
+                double tot = 0.0; for (double v : len) tot += v;
+                double acc = 0.0;
+                for (int q = 0; q < Q; ++q) { acc += len[(size_t)q]; cut[t - b0][(size_t)q + 1] = (int)(ns * acc / tot + 0.5); }
+                cut[t - b0][(size_t)Q] = ns;
+            }
+            for (int q = 0; q < Q; ++q)
+                for (size_t t = b0; t < b1; ++t) {
+                    const Tile& x = T[(size_t)order[t].second];
+                    FFItem it{}; it.type = FF_F; it.i = (unsigned char)x.i; it.c = (unsigned char)x.c; it.q = (unsigned char)q;
+                    it.f.s0 = (unsigned short)cut[t - b0][(size_t)q]; it.f.s1 = (unsigned short)cut[t - b0][(size_t)q + 1];
+                    forder.push_back(it);
+                }
+        }
+    }
     size_t fnext = 0;
     std::multiset<double> events;                       // future times at which the state changes
     // ---- chain state machine
@@ -109,6 +167,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
                 if (ck == 0) diag_ready = tile_done_time(0, 0);
                 if (diag_ready == INF) return;
                 potrf_start[(size_t)ck] = std::max(chain_free + M.boundary, diag_ready);
+                if (trace) fprintf(stderr, "[ff] step %2d potrf start %7.1f (chain free %7.1f, diag ready %7.1f)\n", ck, potrf_start[(size_t)ck], chain_free, diag_ready);
                 potrf_done[(size_t)ck] = potrf_start[(size_t)ck] + M.potrf;
                 events.insert(potrf_start[(size_t)ck]); events.insert(potrf_done[(size_t)ck]);
                 chain_free = potrf_done[(size_t)ck];
@@ -119,6 +178,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
                 const double tw = tile_done_time(ck + 1, ck);
                 if (tw == INF) return;
                 panel_end = std::max(chain_free + M.boundary, tw) + M.crit_panel;
+                if (trace) fprintf(stderr, "[ff]         panel (%d,%d) input %7.1f chain %7.1f\n", ck + 1, ck, tw, chain_free);
                 rowfin[(size_t)ck + 1][(size_t)ck] = panel_end;
                 events.insert(panel_end);
                 chain_free = panel_end;
@@ -127,6 +187,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
             if (cphase == 2) {
                 const double tw = tile_done_time(ck + 1, ck + 1);
                 if (tw == INF) return;
+                if (trace) fprintf(stderr, "[ff]         update (%d,%d) input %7.1f chain %7.1f\n", ck + 1, ck + 1, tw, chain_free);
                 diag_ready = std::max(chain_free + M.boundary, tw) + M.crit_update;
                 events.insert(diag_ready);
                 chain_free = diag_ready;
@@ -160,6 +221,9 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
             const bool panel_ready = x.panel && base_ok && a == x.limit && potrf_done[(size_t)x.c] <= t + 8.0;
             const bool panel_only = panel_ready && x.base_in && pend == 0;
             if (!(pend > 0 || can_base || panel_only)) continue;
+            // a tile whose LAST column is all that is missing waits for its diagonal block, so that update and panel solve
+            // are one pass over the tile -- while there is formation work to do instead
+            if (x.panel && base_ok && a == x.limit && pend <= 1 && !panel_ready && fnext < forder.size()) continue;
             int cls;
             if (x.c <= kc + FF_WINDOW) cls = 0;
             else if (base_ok && a == x.limit) cls = 1;
@@ -177,7 +241,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
             // ---- a formation chunk
             const FFItem it = forder[fnext++];
             Tile& x = T[(size_t)ff_tile(it.i, it.c)];
-            const double fin = t + M.f_overhead + M.stage * M.f_stages;
+            const double fin = t + M.f_overhead + M.stage * (it.f.s1 - it.f.s0);
             x.f_sched++; x.f_time = std::max(x.f_time, fin);
             out.form_end_us = std::max(out.form_end_us, fin);
             events.insert(fin);
@@ -198,21 +262,23 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M, FFSchedu
         const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
         FFItem it{};
         it.type = FF_T; it.i = (unsigned char)x.i; it.c = (unsigned char)x.c;
-        it.j0 = (unsigned char)x.applied; it.j1 = (unsigned char)a;
-        if (x.nitems == 0) it.flags |= FF_INIT;
-        if (fc && !x.base_in) it.flags |= FF_ADD_BASE;
-        const bool base_after = x.base_in || (it.flags & FF_ADD_BASE);
-        double dur = M.t_overhead + M.stage * 4.0 * (a - x.applied) + ((it.flags & FF_ADD_BASE) ? M.t_base : 0.0);
+        it.t.j0 = (unsigned char)x.applied; it.t.j1 = (unsigned char)a;
+        if (x.nitems == 0) it.t.flags |= FF_INIT;
+        if (fc && !x.base_in) it.t.flags |= FF_ADD_BASE;
+        const bool base_after = x.base_in || (it.t.flags & FF_ADD_BASE);
+        double dur = M.t_overhead + M.stage * 4.0 * (a - x.applied) + ((it.t.flags & FF_ADD_BASE) ? M.t_base : 0.0);
         double fin = t + dur;
         if (x.panel && base_after && a == x.limit && potrf_done[(size_t)x.c] <= t + dur + 8.0) {
-            it.flags |= FF_PANEL;
+            it.t.flags |= FF_PANEL;
             fin = std::max(fin, potrf_done[(size_t)x.c]) + M.t_panel;
         }
-        if (x.i == 0 && x.c == 0) it.flags |= FF_SIG_DIAG0;
+        if (x.i == 0 && x.c == 0) it.t.flags |= FF_SIG_DIAG0;
         x.applied = a; x.base_in = base_after; x.nitems++; x.ready = fin;
-        it.seq = (unsigned char)x.nitems;
-        if (it.flags & FF_PANEL) { x.paneled = true; rowfin[(size_t)x.i][(size_t)x.c] = fin; }
+        it.t.seq = (unsigned char)x.nitems;
+        if (it.t.flags & FF_PANEL) { x.paneled = true; rowfin[(size_t)x.i][(size_t)x.c] = fin; }
         if (x.complete()) --remaining;
+        if (trace && getenv("IPM_FF_TRACE")[0] == '2')
+            fprintf(stderr, "[ff] t %7.1f T(%d,%d)[%d,%d) flags %d cls %d -> %7.1f\n", t, x.i, x.c, it.t.j0, it.t.j1, it.t.flags, best_class, fin);
         events.insert(fin);
         out.items.push_back(it);
         free_at.push(Ev(fin, ev.second));

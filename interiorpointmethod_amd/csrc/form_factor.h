@@ -176,7 +176,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
 
         if (it.type == FF_F) {
             // ---- one K-chunk of the formation of tile (ti, tc): raw partial tile -> slab (tile, q)
-            const int s0 = it.q * g.fstages, s1 = min(g.nstages, s0 + g.fstages);
+            const int s0 = it.f.s0, s1 = min(g.nstages, (int)it.f.s1);
             if (s1 > s0)
                 ff_gemm<true, false>(g.A + (int64_t)ti * 128 * g.lda + (int64_t)s0 * FF_BK, g.lda,
                                      g.A + (int64_t)tc * 128 * g.lda + (int64_t)s0 * FF_BK, g.lda, g.d + (int64_t)s0 * FF_BK,
@@ -194,10 +194,11 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         }
 
         // ---- T item: wait for what it needs (one lane, bounded), one acquire
-        const int j0 = it.j0, j1 = it.j1;
+        const int j0 = it.t.j0, j1 = it.t.j1;
+        const int flags = it.t.flags, seq = it.t.seq;
         if (tid == 0) {
-            if (it.flags & FF_ADD_BASE) ff_wait_ge(g.fcount + tile, (unsigned)g.Q, g.timeout);
-            if (!(it.flags & FF_INIT)) ff_wait_ge(g.tprog + tile, (unsigned)it.seq - 1u, g.timeout);
+            if (flags & FF_ADD_BASE) ff_wait_ge(g.fcount + tile, (unsigned)g.Q, g.timeout);
+            if (!(flags & FF_INIT)) ff_wait_ge(g.tprog + tile, (unsigned)seq - 1u, g.timeout);
             if (j1 > j0) {
                 ff_wait_ge(g.lfinal + ti, 4u * (unsigned)j1, g.timeout);
                 if (tc != ti) ff_wait_ge(g.lfinal + tc, 4u * (unsigned)j1, g.timeout);
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) val[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-        if (!(it.flags & FF_INIT)) {
+        if (!(flags & FF_INIT)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) val[i][j][q] = bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16];
         }
-        if (it.flags & FF_ADD_BASE) {
+        if (flags & FF_ADD_BASE) {
             for (int c = 0; c < g.Q; ++c) {
                 const double* sb = g.slab + ((size_t)tile * g.Q + c) * (128 * 128) + er * 128 + ec;
 #pragma unroll
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) val[i][j] -= acc[i][j];
-        if (ti == tc && (it.flags & FF_ADD_BASE)) {
+        if (ti == tc && (flags & FF_ADD_BASE)) {
             // padding rows of the normal matrix carry a unit diagonal (their rows of A are zero)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
                         if (r == c && ti * 128 + r >= g.m) val[i][j][q] = 1.0;
                     }
         }
-        if (it.flags & FF_PANEL) {
+        if (flags & FF_PANEL) {
             // L(ti,tc) = tile inv(L(tc,tc))^T: the tile goes back through LDS stage by stage as the P operand
             if (tid == 0) {
                 ff_wait_ge(g.potrfdone + tc, 1u, g.timeout);
@@ -277,9 +278,9 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
                 for (int q = 0; q < 4; ++q) bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16] = val[i][j][q];
         ff_publish_begin();
         if (tid == 0) {
-            __hip_atomic_store(g.tprog + tile, (unsigned)it.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (it.flags & FF_PANEL) __hip_atomic_fetch_add(g.lfinal + ti, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (it.flags & FF_SIG_DIAG0) __hip_atomic_fetch_add(g.dready, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.tprog + tile, (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (flags & FF_PANEL) __hip_atomic_fetch_add(g.lfinal + ti, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (flags & FF_SIG_DIAG0) __hip_atomic_fetch_add(g.dready, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

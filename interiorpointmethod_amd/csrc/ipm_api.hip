@@ -27,6 +27,7 @@
 #include "sparse_chol.h"
 #include "sparse_symbolic.h"
 #include "vector_ops.h"
+#include "form_factor.h"
 
 #include <algorithm>
 #include <atomic>
@@ -130,6 +131,20 @@ struct ipm_handle {
     double *y = nullptr, *b = nullptr, *rb = nullptr, *t1 = nullptr, *t2 = nullptr, *dya = nullptr, *dy = nullptr;
     double *atp = nullptr, *part = nullptr, *slab = nullptr;
     int form_variant = 0;
+    // fused formation + factorization (form_factor.h): dense handles of FF_MIN_NBLK .. FF_MAX_NBLK blocks that have the device to
+    // themselves run ONE persistent worker launch beside the pivot chain instead of formation followed by factorization
+    int ff_enabled = 1;                   // IPM_FUSED_FACTOR=0 disables, =force also below FF_MIN_NBLK blocks (tests)
+    int ff_min_nblk = 16, ff_max_nblk = 40;   // beyond ~48 blocks the two-level serial schedule is the measured default (IPM_FF_MAX_NBLK)
+    int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
+    int ff_workers = 0;                   // workgroups of the persistent launch (IPM_FF_WORKERS; default: CUs - 8)
+    bool ff_built = false, ff_last = false;
+    FFSchedule ff_sched;
+    FFItem* d_ff_items = nullptr;
+    unsigned* d_ff_flags = nullptr;       // ticket[16] | maxdiag ticket[16] | fcount[ntile] | tprog[ntile] | lfinal[nblk] | dready[nblk] | potrfdone[nblk]
+    size_t ff_flag_words = 0;
+    double* ff_slab = nullptr;            // [ntile][Q][128*128]
+    double* ff_part = nullptr;            // [256] block maxima of ff_maxdiag_kernel
+    hipEvent_t ev_ffjoin = nullptr;
     const int* fdone = nullptr;           // `done` word the formation / factorization kernels test (null: Scalars::done; the overlapped
                                           // path points it at the per-iteration latch Scalars::done_f)
     // Tile envelope (skyline) of A A^T for sparse handles, from the structure of A in the caller's row order:
@@ -496,6 +511,11 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
+    if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; } else h->ff_enabled = atoi(e); }
+    if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
+    if (const char* e = getenv("IPM_FF_Q")) h->ff_q = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = getenv("IPM_FF_WORKERS")) h->ff_workers = std::max(1, atoi(e));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_ffjoin, hipEventDisableTiming));
     if (const char* e = getenv("IPM_RESIDUAL_STEP")) h->residual_step = atoi(e);
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
     for (int k = 0; k < h->nblk; ++k) {
@@ -532,11 +552,13 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev_res) (void)hipEventDestroy(h->ev_res);
     if (h->ev_grp) (void)hipEventDestroy(h->ev_grp);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
+    if (h->ev_ffjoin) (void)hipEventDestroy(h->ev_ffjoin);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
-    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart})
+    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
+                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part})
         dev_free(h->device, h->stream, p);
     free_sparse_factor(h);
     for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
@@ -1433,6 +1455,149 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
     return IPM_OK;
 }
 
+// ------------------------------------------------------------------------------- fused formation + factorization
+// Can this iteration run the fused path?  (mirrors the `fs` rule of enqueue_factor: device-polled hand-offs need the
+// device to themselves; a recovered poll time-out clears flag_sync and with it this path, for good)
+static bool ff_ok(const ipm_handle* h) {
+    if (!h->ff_enabled || h->sparse || h->lookahead == 0 || h->stream2 == nullptr || h->flag_sync == 0) return false;
+    if (h->nblk < h->ff_min_nblk || h->nblk > std::min(h->ff_max_nblk, FF_MAX_NBLK) || h->np % FF_BK) return false;
+    return h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
+}
+
+// schedule + device buffers, once per handle
+static int ff_build(ipm_handle* h) {
+    if (h->ff_built) return IPM_OK;
+    if (h->ff_workers <= 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
+        // one workgroup per CU (136 KB of LDS each) on all CUs but eight: those stay empty for the pivot chain's kernels
+        h->ff_workers = std::max(8, prop.multiProcessorCount - 8);
+    }
+    const int nstages = (int)(h->np / FF_BK);
+    const int Q = std::max(1, std::min(h->ff_q, nstages));
+    h->ff_q = Q;
+    FFModel M;
+    M.f_stages = (nstages + Q - 1) / Q; M.nstages = nstages;
+    ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched);
+    const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
+    {   // every tile complete?  (an incomplete list would be an internal error of the scheduler, never a reason to hang a GPU)
+        std::vector<int> fcnt(ntile, 0), base(ntile, 0), applied(ntile, 0), paneled(ntile, 0);
+        for (const FFItem& it : h->ff_sched.items) {
+            const size_t t = (size_t)ff_tile(it.i, it.c);
+            if (it.type == FF_F) { fcnt[t]++; continue; }
+            if (it.t.j0 != applied[t]) return fail(h, IPM_ERR_INVALID_ARG, "fused factor: internal error (column order of tile %d,%d)", it.i, it.c);
+            applied[t] = it.t.j1;
+            if (it.t.flags & FF_ADD_BASE) base[t]++;
+            if (it.t.flags & FF_PANEL) paneled[t]++;
+        }
+        for (int i = 0; i < h->nblk; ++i)
+            for (int c = 0; c <= i; ++c) {
+                const size_t t = (size_t)ff_tile(i, c);
+                if (fcnt[t] != Q || base[t] != 1 || applied[t] != ff_limit(i, c) || paneled[t] != (ff_needs_panel(i, c) ? 1 : 0))
+                    return fail(h, IPM_ERR_INVALID_ARG, "fused factor: internal error (tile %d,%d incomplete in the work list)", i, c);
+            }
+    }
+    const size_t nit = h->ff_sched.items.size();
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * nit));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, h->ff_sched.items.data(), sizeof(FFItem) * nit, hipMemcpyHostToDevice, h->stream));
+    h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk;
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * h->ff_flag_words));
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)Q * 128 * 128));
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_part, sizeof(double) * 256));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->ff_built = true;
+    return IPM_OK;
+}
+
+// One persistent worker launch (formation chunks + every update / panel solve outside the pivot chain) on the main stream and
+// the pivot chain -- potrf_diag(k), panel solve of tile (k+1,k), update of tile (k+1,k+1) -- on the second stream, coupled
+// through device counters only.  `ev` (optional): ev[1] / ev[2] bracket the worker launch.
+static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int ginv_step) {
+    int rc = ff_build(h);
+    if (rc) return rc;
+    const int nblk = h->nblk;
+    const size_t ntile = (size_t)nblk * (nblk + 1) / 2;
+    const int* done = h->fdone ? h->fdone : &h->sc->done;
+    hipStream_t sw = h->stream, sm = h->stream2;
+    unsigned* F = h->d_ff_flags;
+    unsigned *ticket = F, *mticket = F + 16, *fcount = F + 32, *tprog = fcount + ntile, *lfinal = tprog + ntile, *dready = lfinal + nblk,
+             *potrfdone = dready + nblk;
+    unsigned* timeout = h->d_flags + 2 * (size_t)nblk;
+    HIP_TRY(h, hipMemsetAsync(F, 0, sizeof(unsigned) * h->ff_flag_words, sw));
+    // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end here)
+    hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sw, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
+                       &h->sc->maxdiag, done);
+    HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
+    HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
+    FFArgs a;
+    memset(&a, 0, sizeof a);
+    a.A = h->A; a.lda = h->np; a.d = h->d; a.B = h->B; a.ldb = h->mp; a.invD = h->invD; a.slab = h->ff_slab;
+    a.items = h->d_ff_items; a.nitems = (int)h->ff_sched.items.size();
+    a.ticket = ticket; a.fcount = fcount; a.tprog = tprog; a.lfinal = lfinal; a.dready = dready; a.potrfdone = potrfdone;
+    a.timeout = timeout; a.done = done;
+    a.nblk = nblk; a.Q = h->ff_q; a.nstages = (int)(h->np / FF_BK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
+    if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
+    hipLaunchKernelGGL(form_factor_kernel, dim3((unsigned)h->ff_workers), dim3(FF_THREADS), 0, sw, a);
+    if (ev) HIP_TRY(h, hipEventRecord(ev[2], sw));
+    HIP_TRY(h, hipGetLastError());
+    h->n_counter_steps = 0; h->n_event_steps = 0; h->last_gs = 1;
+    for (int k = 0; k < nblk; ++k) {
+        PotrfDiag pd;
+        pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
+        pd.inv = h->invD + (int64_t)k * NB * NB;
+        pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
+        pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
+        pd.wait_on = dready + k; pd.wait_count = 10; pd.signal = potrfdone + k; pd.timeout = timeout;
+        hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
+        ++h->n_counter_steps;
+        if (k == ginv_step) {
+            HIP_TRY(h, hipEventRecord(h->ev_grp, sm));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
+            int rc_ = enqueue_group_inverses(h, 0, (k + 1) / h->gsz, h->stream3);
+            if (rc_) return rc_;
+        }
+        if (k == mid_step) { int rc_ = enqueue_residual_stream(h, sm); if (rc_) return rc_; }
+        if (k + 1 >= nblk) break;
+        double* panel = h->B + (int64_t)(k + 1) * NB * h->mp + (int64_t)k * NB;
+        GemmNT tc = gemm_defaults();                                // L(k+1,k) = tile inv(L_kk)^T, in place
+        tc.tile_order = nullptr; tc.batch = 1; tc.batch2 = 1;
+        tc.P = panel; tc.ldp = h->mp; tc.Q = pd.inv; tc.ldq = NB; tc.w = nullptr;
+        tc.C = panel; tc.ldc = h->mp; tc.M = NB; tc.N = NB; tc.K = NB;
+        tc.alpha = 1.0; tc.beta = 0.0; tc.lower = 0; tc.unit_diag_from = -1; tc.done = done;
+        tc.wait_on = tprog + ff_tile(k + 1, k); tc.wait_count = (unsigned)h->ff_sched.tile_items[(size_t)ff_tile(k + 1, k)];
+        tc.signal = lfinal + (k + 1); tc.timeout = timeout;         // four workgroups, one count each: 4 = one final tile
+        HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));
+        GemmNT uc = gemm_defaults();                                // tile (k+1,k+1) -= L(k+1,k) L(k+1,k)^T
+        uc.tile_order = nullptr; uc.batch = 1; uc.batch2 = 1;
+        uc.P = panel; uc.ldp = h->mp; uc.Q = panel; uc.ldq = h->mp; uc.w = nullptr;
+        uc.C = h->B + (int64_t)(k + 1) * NB * (h->mp + 1); uc.ldc = h->mp; uc.M = NB; uc.N = NB; uc.K = NB;
+        uc.alpha = -1.0; uc.beta = 1.0; uc.lower = 1; uc.unit_diag_from = -1; uc.done = done;
+        uc.wait_on = tprog + ff_tile(k + 1, k + 1); uc.wait_count = (unsigned)h->ff_sched.tile_items[(size_t)ff_tile(k + 1, k + 1)];
+        uc.signal = dready + (k + 1); uc.timeout = timeout;         // ten 32 x 32 sub-tiles, one count each
+        HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_ffjoin, sm));
+    HIP_TRY(h, hipStreamWaitEvent(sw, h->ev_ffjoin, 0));
+    HIP_TRY(h, hipGetLastError());
+    h->ff_last = true;
+    return IPM_OK;
+}
+
+extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, unsigned char* items, int32_t capacity, int32_t* count,
+                                     int32_t* tile_items, double sim_us[2]) {
+    if (nblk < 1 || nblk > FF_MAX_NBLK || q < 1 || q > 16 || workers < 1 || !count) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_debug_ff_schedule: bad arguments");
+    static_assert(sizeof(FFItem) == 8, "work item layout");
+    FFSchedule S;
+    FFModel M;
+    M.f_stages = std::max(1, 256 / q); M.nstages = 256;       // K = 8192 (the headline size's formation)
+    ff_build_schedule(nblk, q, workers, M, S);
+    *count = (int32_t)S.items.size();
+    if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));
+    if (tile_items) for (size_t t = 0; t < S.tile_items.size(); ++t) tile_items[t] = S.tile_items[t];
+    if (sim_us) { sim_us[0] = S.makespan_us; sim_us[1] = S.form_end_us; }
+    return IPM_OK;
+}
+
 // X_g, XT_g = inv of every 1024 x 1024 diagonal group of the factor and its transpose (trsv_grouped.h):
 // recursive doubling 128 -> 256 -> 512 -> 1024, three GEMMs per level batched over (pairs in a group,
 // groups).  After enqueue_factor, on the main stream.
@@ -1637,20 +1802,25 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         // stream under the chain-bound tail of the factorization
         VecArgs a = vec_args(h);
         hipLaunchKernelGGL(scaling_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
-        if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+        if (ev && !ff_ok(h)) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         // the stop test of THIS iterate runs on the residual stream while the factorization is in flight: formation and
         // factorization test the latch scaling_kernel took (Scalars::done_f), so they either run whole or not at all and
         // after a converged solve B / invD hold the complete factor of the final iterate (ipm_get_factor, pivots_fixed)
         struct Latch { ipm_handle* h; ~Latch() { h->fdone = nullptr; } } latch{h};
         h->fdone = &h->sc->done_f;
-        if ((rc = enqueue_form(h, h->d))) return rc;
-        if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+        h->ff_last = false;
+        const bool fused = ff_ok(h);
+        if (!fused) {
+            if ((rc = enqueue_form(h, h->d))) return rc;
+            if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+        }
         // start late in the chain-bound tail: the three passes need ~0.2 ms, six steps of the chain.  Measured at 32 blocks
         // (it/s for a start at step 0 / 4 / 12 / 20 / 26 / 30): 199.5 / 199.6 / 200.6 / 201.0 / 203.1 / 200.5
         const int rstep = h->residual_step >= 0 ? std::min(h->residual_step, h->nblk - 1) : h->nblk * 13 / 16;
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
         const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
-        if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
+        if (fused) { if ((rc = enqueue_form_factor(h, ev, rstep, gstep))) return rc; }
+        else if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
         h->fdone = nullptr;
         if (gstep >= 0) {
             // the last group's inverse (nine dependent launches, ~80 us) goes to the residual stream as well: the forward
@@ -1672,10 +1842,17 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     }
     if (all) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if ((rc = enqueue_residuals(h))) return rc;
-    if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
-    if ((rc = enqueue_form(h, h->d))) return rc;
-    if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-    if ((rc = enqueue_factor(h, true))) return rc;
+    h->ff_last = false;
+    if (ff_ok(h) && h->profiling < 2) {
+        // (handles below 16 blocks have no residual stream: the fused launch is used here only when IPM_FUSED_FACTOR=force
+        //  lowers the block limit -- the tests' way to run the fused kernels at small sizes)
+        if ((rc = enqueue_form_factor(h, ev, -1, -1))) return rc;
+    } else {
+        if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+        if ((rc = enqueue_form(h, h->d))) return rc;
+        if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
+        if ((rc = enqueue_factor(h, true))) return rc;
+    }
     if ((rc = enqueue_group_inverses(h))) return rc;
     if (all) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
     if ((rc = enqueue_predictor(h, all ? ev + 4 : nullptr))) return rc;
@@ -2012,13 +2189,14 @@ extern "C" int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capa
     return IPM_OK;
 }
 
-extern "C" int ipm_get_schedule(ipm_handle* h, int32_t out[10]) {
+extern "C" int ipm_get_schedule(ipm_handle* h, int32_t out[12]) {
     if (!h || !out) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_schedule: bad arguments");
     const int live = h->device < MAX_DEVICES ? g_live[h->device].load(std::memory_order_acquire) : 1;
     out[0] = h->nblk; out[1] = h->last_gs; out[2] = h->grouped_trsv;
     out[3] = (may_poll(h) && live <= 1) ? 1 : 0;
     out[4] = h->n_counter_steps; out[5] = h->n_event_steps; out[6] = h->use_env ? 1 : 0; out[7] = live;
     out[8] = h->timeouts_recovered; out[9] = h->small ? 1 : 0;
+    out[10] = h->ff_last ? 1 : 0; out[11] = (h->spf && sp_level(h)) ? 1 : 0;
     return IPM_OK;
 }
 

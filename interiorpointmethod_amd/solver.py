@@ -348,10 +348,10 @@ class IpmSolver:
 
     def schedule(self):
         """How the handle runs its factorization (ipm_get_schedule): dict for tests and diagnostics."""
-        out = (C.c_int32 * 10)()
+        out = (C.c_int32 * 12)()
         self._check(self._lib.ipm_get_schedule(self._h, out))
         keys = ("blocks", "group_steps", "grouped_trsv", "device_polling", "counter_steps", "event_steps", "envelope",
-                "live_handles", "timeouts_recovered", "fused_small")
+                "live_handles", "timeouts_recovered", "fused_small", "fused_factor", "sparse_level_mode")
         return dict(zip(keys, (int(v) for v in out)))
 
     def factor_info(self):

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(built_lib):
 
 def test_abi_version_and_host_only_calls(built_lib):
     lib = ipm.load_library()
-    assert lib.ipm_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ipm_abi_version() == _lib.ABI_VERSION == 4
     opts = _lib.Options()
     lib.ipm_default_options(C.byref(opts))
     assert opts.eta == 0.91 and opts.pivot_guard_big == 1e64 and opts.check_every >= 1   # main.py:607

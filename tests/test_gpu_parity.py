@@ -1000,7 +1000,7 @@ def test_plain_c_driver():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.strip().splitlines()
-    assert lines[0].startswith("libipm_hip ABI 3")
+    assert lines[0].startswith("libipm_hip ABI 4")
     ex1 = dict(zip(lines[1].split()[1::2], lines[1].split()[2::2]))
     assert ex1["status"] == "1" and abs(float(ex1["objective"]) + 775.0) < 1e-6 and int(ex1["iterations"]) == 17
     assert "random 300x700: status 1" in lines[2]

@@ -4,7 +4,8 @@
 //
 // What is being scheduled (dense handles, 128 x 128 tiles (i, c), i >= c, of B = A D^2 A^T and of its Cholesky factor;
 // replaces main.py:224 + the factorization inside main.py:180/:226 of the reference, fused):
-//   F(i,c,q)          one of Q K-chunks of the formation of tile (i,c): a raw partial tile into slab (tile, q)
+//   F(i,c,q)          one of Q K-chunks of the formation of the tile PAIR (i,c), (i+1,c), i even: raw partial tiles into the
+//                     slabs (tile, q) of the two tiles (a half above the diagonal or below the matrix is dropped)
 //   T(i,c,[j0,j1))    tile (i,c) -= sum_{j0<=j<j1} L(i,j) L(c,j)^T, optionally + the Q formation slabs (ADD_BASE, once per
 //                     tile, any time after its F chunks), optionally followed by the panel solve L(i,c) = tile inv(L(c,c))^T
 //                     (PANEL, once, after everything else of the tile and after the diagonal block c is factored)
@@ -61,14 +62,17 @@ constexpr int FF_MAX_NBLK = 96;
 FF_HD inline int ff_tile(int i, int c) { return i * (i + 1) / 2 + c; }
 
 struct FFModel {                       // durations in microseconds (MI355X, one 512-thread workgroup per CU)
-    double stage = 3.5;                // one BK = 32 stage of a 128 x 128 tile
-    double f_overhead = 6.0;           // F chunk: prologue + slab store + release
-    double t_overhead = 7.0;           // T item: wait + acquire + tile load / store + release
-    double t_base = 2.0;               // reading Q slabs
-    double t_panel = 16.0;             // second product with inv(L_cc) (4 stages + staging through LDS)
+    double stage = 4.6;                // one BK = 32 stage of a 128 x 128 tile (update / panel items; 4.2-4.4 standalone)
+    double pstage = 4.4;               // one BK = 16 stage of a 256 x 128 tile PAIR (formation): 9280 cycles at the 2.1 GHz the
+                                       // chip holds inside the fused launch (in-kernel cycle profile; 3.91 us standalone)
+    double f_overhead = 8.0;           // F chunk: prologue + slab stores + drain
+    double t_overhead = 14.0;          // T item: ticket, wait + acquire, tile load, combine, store + drain (cycle profile: 10.5 + 3 us)
+    double t_base = 4.0;               // reading Q slabs
+    double t_panel = 19.0;             // second product with inv(L_cc) (4 stages + staging through LDS; profile: 19 us)
+    int batch = 4, window = 2;         // columns per deferred batch; chain look-ahead (FF_BATCH / FF_WINDOW)
     double potrf = 38.0, crit_panel = 8.0, crit_update = 6.0, boundary = 3.0;
-    int f_stages = 64;                 // stages per F chunk (set by the caller: ceil(K / 32 / Q))
-    int nstages = 256;                 // K / 32 of the formation
+    int f_stages = 128;                // stages per F chunk (set by the caller: ceil(K / 16 / Q))
+    int nstages = 512;                 // K / 16 of the formation
     int stagger = 1;                   // spread the chunk lengths of the first band (see ff_build_schedule)
     int row_weight = 10, col_weight = 40;   // formation order key = row_weight (i - 1) + col_weight c (see ff_build_schedule)
 };
@@ -92,6 +96,8 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     if (const char* e = getenv("IPM_FF_ROW_WEIGHT")) Mx.row_weight = atoi(e);
     if (const char* e = getenv("IPM_FF_COL_WEIGHT")) Mx.col_weight = atoi(e);
     if (const char* e = getenv("IPM_FF_STAGGER")) Mx.stagger = atoi(e);
+    if (const char* e = getenv("IPM_FF_BATCH")) Mx.batch = std::max(1, atoi(e));
+    if (const char* e = getenv("IPM_FF_WINDOW")) Mx.window = std::max(1, atoi(e));
     const FFModel& M = Mx;
     struct Tile {
         int i, c, limit; bool panel;
@@ -118,15 +124,20 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     // Inside a band of W / Q consecutive tiles the chunks go q-major, so the W concurrent items are W / Q tiles x Q chunks.
     std::vector<FFItem> forder;
     {
-        std::vector<std::pair<int, int>> order;             // (key, tile)
-        for (int i = 0; i < nblk; ++i)
-            for (int c = 0; c <= i; ++c) order.emplace_back(M.row_weight * std::max(i - 1, 0) + M.col_weight * c, ff_tile(i, c));
-        std::stable_sort(order.begin(), order.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
-            if (a.first != b.first) return a.first < b.first;
-            return T[(size_t)a.second].c < T[(size_t)b.second].c;
-        });
-        // Chunk boundaries in stages.  Uniform, except for the FIRST band (the items every worker starts with): there the
-        // chunk lengths are spread over 0.4 .. 1.6 of the mean, so that the workers do not finish their formation chunks in
+        // formation items are tile PAIRS (2r, c), (2r + 1, c) (form_factor.h: 256 x 128 blocks); a pair is needed when its
+        // more urgent tile is
+        struct Pair { int key, i, c; };
+        std::vector<Pair> order;
+        for (int i = 0; i < nblk; i += 2)
+            for (int c = 0; c <= std::min(i + 1, nblk - 1); ++c) {
+                int key = 1 << 30;
+                if (c <= i) key = std::min(key, M.row_weight * std::max(i - 1, 0) + M.col_weight * c);
+                if (i + 1 < nblk) key = std::min(key, M.row_weight * i + M.col_weight * c);
+                order.push_back(Pair{key, i, c});
+            }
+        std::stable_sort(order.begin(), order.end(), [&](const Pair& a, const Pair& b) { return a.key != b.key ? a.key < b.key : a.c < b.c; });
+        // Chunk boundaries in (BK = 16) stages.  Uniform, except for the FIRST band (the items every worker starts with): there
+        // the chunk lengths are spread over 0.4 .. 1.6 of the mean, so that the workers do not finish their formation chunks in
         // lockstep -- with equal chunks all of them are deaf for one whole chunk (hundreds of microseconds) at the same time,
         // and everything the chain waits for waits with them; staggered, one worker comes free every microsecond or so.
         const int ns = M.nstages;
@@ -147,8 +158,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
             }
             for (int q = 0; q < Q; ++q)
                 for (size_t t = b0; t < b1; ++t) {
-                    const Tile& x = T[(size_t)order[t].second];
-                    FFItem it{}; it.type = FF_F; it.i = (unsigned char)x.i; it.c = (unsigned char)x.c; it.q = (unsigned char)q;
+                    FFItem it{}; it.type = FF_F; it.i = (unsigned char)order[t].i; it.c = (unsigned char)order[t].c; it.q = (unsigned char)q;
                     it.f.s0 = (unsigned short)cut[t - b0][(size_t)q]; it.f.s1 = (unsigned short)cut[t - b0][(size_t)q + 1];
                     forder.push_back(it);
                 }
@@ -225,9 +235,9 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
             // are one pass over the tile -- while there is formation work to do instead
             if (x.panel && base_ok && a == x.limit && pend <= 1 && !panel_ready && fnext < forder.size()) continue;
             int cls;
-            if (x.c <= kc + FF_WINDOW) cls = 0;
+            if (x.c <= kc + M.window) cls = 0;
             else if (base_ok && a == x.limit) cls = 1;
-            else if (pend >= FF_BATCH) cls = 2;
+            else if (pend >= M.batch) cls = 2;
             else if (can_base && pend == 0 && x.applied == 0 && fnext < forder.size()) continue;   // nothing but the base yet: wait for columns
             else cls = 4;
             if (cls == 4 && fnext < forder.size()) continue;       // small deferred batches only once the formation is exhausted
@@ -240,9 +250,9 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
         if (best < 0 && fnext < forder.size()) {
             // ---- a formation chunk
             const FFItem it = forder[fnext++];
-            Tile& x = T[(size_t)ff_tile(it.i, it.c)];
-            const double fin = t + M.f_overhead + M.stage * (it.f.s1 - it.f.s0);
-            x.f_sched++; x.f_time = std::max(x.f_time, fin);
+            const double fin = t + M.f_overhead + M.pstage * (it.f.s1 - it.f.s0);
+            if (it.c <= it.i) { Tile& x = T[(size_t)ff_tile(it.i, it.c)]; x.f_sched++; x.f_time = std::max(x.f_time, fin); }
+            if (it.i + 1 < nblk) { Tile& x = T[(size_t)ff_tile(it.i + 1, it.c)]; x.f_sched++; x.f_time = std::max(x.f_time, fin); }
             out.form_end_us = std::max(out.form_end_us, fin);
             events.insert(fin);
             out.items.push_back(it);

@@ -48,17 +48,30 @@ struct FFArgs {
     unsigned* dready;                  // [nblk] diagonal tile k ready for potrf_diag (>= 10)
     const unsigned* potrfdone;         // [nblk] diagonal block k factored, inv(L_kk) written (>= 1)
     unsigned* timeout;
+    unsigned* dbg;                     // [8] diagnostic (first wait that gave up), may be null
+    unsigned dbg_words;                // hand-off words to snapshot on that occasion (0: none)
+    long long* prof;                   // diagnostic (may be null): [workgroups][16] cycles per phase (s_memtime), see FF_PROF
     const int* done;
-    int nblk, Q, nstages, fstages;     // nstages = K / 32 of the formation, fstages = stages per chunk
+    int nblk, Q, nstages, fstages;     // nstages = K / 16 of the formation (BK = 16 stages of the pair engine), fstages = stages per chunk
     int m;                             // true rows: padding rows get a unit diagonal
 };
 
-__device__ __forceinline__ void ff_wait_ge(const unsigned* p, unsigned v, unsigned* timeout) {
+// dbg (optional, 8 words, zeroed per launch): the FIRST wait of the launch that gave up records {1, item, kind, target, seen}
+__device__ __forceinline__ void ff_wait_ge(const unsigned* p, unsigned v, unsigned* timeout, unsigned* dbg = nullptr, unsigned item = 0,
+                                           unsigned kind = 0, unsigned nw = 0) {
     unsigned spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) {
         __builtin_amdgcn_s_sleep(2);
         ++spins;
         if (spins > (1u << 22) || ((spins & 1023u) == 1u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (spins > (1u << 22) && dbg && __hip_atomic_fetch_add(dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                dbg[1] = item; dbg[2] = kind; dbg[3] = v; dbg[4] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // snapshot of every hand-off word BEFORE the time-out word releases the other waiters (dbg[5] = words, the
+                // copy sits right behind the live words)
+                const unsigned* live = dbg - 24;
+                unsigned* snap = const_cast<unsigned*>(live) + nw;
+                for (unsigned w = 0; w < nw; ++w) snap[w] = __hip_atomic_load(live + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
@@ -138,15 +151,204 @@ __device__ __forceinline__ void ff_gemm(const double* __restrict__ Pg, int64_t l
     }
 }
 
-// every storing wave drains, the workgroup meets, ONE lane releases (agent scope); the caller then bumps its counters
+// The same product, software pipelined (the schedule of adat_syrk_f64.h carried over to 8 waves and BK = 32): fragment
+// reads run one k-step ahead through two register sets; the next stage's operands -- fetched from memory a whole stage
+// earlier -- are written to the other LDS buffer between the MFMAs of the second-to-last k-step; the stage barrier follows,
+// and the LAST k-step's eight MFMAs (fragments already in registers) issue right behind it while the first fragments of the
+// next stage are read.  A wave's MFMA stream therefore continues across the barrier, and no LDS or memory latency sits in
+// front of an MFMA.  Same operand tiles, same summation order as ff_gemm: results are bit-identical to it.
+template <bool SCALE>
+__device__ __forceinline__ void ff_gemm_pipe(const double* __restrict__ Pg, int64_t ldp, const double* __restrict__ Qg, int64_t ldq,
+                                             const double* __restrict__ w, int ns, double* lds, f64x4 (&acc)[4][2]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fk = lane >> 4;
+    double* Ps = lds;
+    double* Qs = lds + 2 * FF_OP;
+    const int ch = tid & 15, r0 = tid >> 4;
+    const double* pP = Pg + (int64_t)r0 * ldp + ch * 2;
+    const double* pQ = Qg + (int64_t)r0 * ldq + ch * 2;
+    f64x2 pr[4], qr[4], wr;
+    auto issue_loads = [&](int s) {
+        if (SCALE) wr = *reinterpret_cast<const f64x2*>(w + (int64_t)s * FF_BK + ch * 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qr[u] = *reinterpret_cast<const f64x2*>(pQ + (int64_t)u * 32 * ldq + (int64_t)s * FF_BK);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pr[u] = *reinterpret_cast<const f64x2*>(pP + (int64_t)u * 32 * ldp + (int64_t)s * FF_BK);
+    };
+    const int st_off = r0 * FF_LDT + ch * 2;
+    auto store_q = [&](int buf, int u) {
+        f64x2 v = qr[u];
+        if (SCALE) { v.x *= wr.x; v.y *= wr.y; }
+        *reinterpret_cast<f64x2*>(Qs + buf * FF_OP + u * 32 * FF_LDT + st_off) = v;
+    };
+    auto store_p = [&](int buf, int u) { *reinterpret_cast<f64x2*>(Ps + buf * FF_OP + u * 32 * FF_LDT + st_off) = pr[u]; };
+    const int fa_off = (wm * 64 + fr) * FF_LDT + fk, fb_off = (wn * 32 + fr) * FF_LDT + fk;
+    double fa[2][4], fb[2][2];
+    auto read_frags = [&](int set, int buf, int kk) {
+        const double* pa = Ps + buf * FF_OP + fa_off + kk * 4;
+        const double* qb = Qs + buf * FF_OP + fb_off + kk * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = pa[i * 16 * FF_LDT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = qb[j * 16 * FF_LDT];
+    };
+    auto mfma8 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    // prologue: stage 0 in LDS, loads of stage 1 in flight, first fragments in set 0
+    issue_loads(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { store_q(0, u); store_p(0, u); }
+    __syncthreads();
+    if (1 < ns) issue_loads(1);
+    read_frags(0, 0, 0);
+    for (int s = 0; s < ns; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < ns;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {                      // k-steps 0 .. 5: prefetch kk + 1, multiply kk
+            read_frags((kk + 1) & 1, buf, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(kk & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frags(1, buf, 7);                                // fragments of the last k-step, before the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 6, with the next stage's operands written to the other LDS buffer between its MFMA rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+            if (more) { store_q(buf ^ 1, i); store_p(buf ^ 1, i); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                      // stage s + 1 visible; every read of stage s is issued
+        if (s + 2 < ns) issue_loads(s + 2);
+        if (more) read_frags(0, buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(1);                                             // k-step 7
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                          // (the caller may reuse the LDS at once)
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// FORMATION engine: TWO vertically adjacent tiles at once -- a 256 x 128 block of B = A diag(d) A^T -- by the 8 waves as
+// 4 (M) x 2 (N), each wave 64 x 64 = 4 x 4 MFMA tiles: per wave exactly the proven schedule of adat_syrk_f64.h (16 MFMAs per
+// k-step against 8 fragment reads, BK = 16 stages, fragment reads one k-step ahead, next stage written to LDS under the
+// third k-step, barrier, last k-step behind it), and the column panel (Q operand, with the d scaling) is fetched once for
+// both tiles.  acc: [4][4] per wave; rows of the block = wm * 64 + ..., i.e. waves 0-3 hold the upper tile, 4-7 the lower.
+constexpr int FF_PBK = 16, FF_PLDT = FF_PBK + 2;
+constexpr int FF_POP_P = 256 * FF_PLDT, FF_POP_Q = 128 * FF_PLDT;     // doubles of the P / Q tile of one stage
+static_assert(2 * (FF_POP_P + FF_POP_Q) <= FF_LDS_DOUBLES, "pair engine LDS");
+
+// P0 / P1: first row of the upper / lower tile's 128-row panel of A (an invalid half is given any valid panel).
+__device__ __forceinline__ void ff_gemm_pair(const double* __restrict__ P0, const double* __restrict__ P1, const double* __restrict__ Qg,
+                                             int64_t ld, const double* __restrict__ w, int ns, double* lds, f64x4 (&acc)[4][4]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    double* Ps = lds;                            // [2][256][18]
+    double* Qs = lds + 2 * FF_POP_P;             // [2][128][18]
+    // staging: thread -> 16-byte chunk ch (of 8) of rows r0 + 64 u: P u < 4 (256 rows), Q u < 2 (128 rows)
+    const int ch = tid & 7, r0 = tid >> 3;
+    const double* pP0 = P0 + (int64_t)r0 * ld + ch * 2;
+    const double* pP1 = P1 + (int64_t)r0 * ld + ch * 2;
+    const double* pQ = Qg + (int64_t)r0 * ld + ch * 2;
+    f64x2 pr[4], qr[2], wr;
+    auto issue_loads = [&](int s) {
+        wr = *reinterpret_cast<const f64x2*>(w + (int64_t)s * FF_PBK + ch * 2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) qr[u] = *reinterpret_cast<const f64x2*>(pQ + (int64_t)u * 64 * ld + (int64_t)s * FF_PBK);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pr[u] = *reinterpret_cast<const f64x2*>(pP0 + (int64_t)u * 64 * ld + (int64_t)s * FF_PBK);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pr[2 + u] = *reinterpret_cast<const f64x2*>(pP1 + (int64_t)u * 64 * ld + (int64_t)s * FF_PBK);
+    };
+    const int st_off = r0 * FF_PLDT + ch * 2;
+    auto store_q = [&](int buf, int u) {
+        f64x2 v = qr[u];
+        v.x *= wr.x; v.y *= wr.y;
+        *reinterpret_cast<f64x2*>(Qs + buf * FF_POP_Q + u * 64 * FF_PLDT + st_off) = v;
+    };
+    auto store_p = [&](int buf, int u) { *reinterpret_cast<f64x2*>(Ps + buf * FF_POP_P + u * 64 * FF_PLDT + st_off) = pr[u]; };
+    const int fa_off = (wm * 64 + fr) * FF_PLDT + fk, fb_off = (wn * 64 + fr) * FF_PLDT + fk;
+    double fa[2][4], fb[2][4];
+    auto read_frags = [&](int set, int buf, int kk) {
+        const double* pa = Ps + buf * FF_POP_P + fa_off + kk * 4;
+        const double* qb = Qs + buf * FF_POP_Q + fb_off + kk * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = pa[i * 16 * FF_PLDT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = qb[j * 16 * FF_PLDT];
+    };
+    auto mfma16 = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+    };
+    issue_loads(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) store_q(0, u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) store_p(0, u);
+    __syncthreads();
+    if (1 < ns) issue_loads(1);
+    read_frags(0, 0, 0);
+    for (int s = 0; s < ns; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < ns;
+        read_frags(1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(0);                                              // k-step 0
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(0, buf, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(1);                                              // k-step 1
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(1, buf, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-step 2, with the next stage's operands written to the other LDS buffer between its MFMA rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+            if (more) { if (i < 2) store_q(buf ^ 1, i); store_p(buf ^ 1, i); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (s + 2 < ns) issue_loads(s + 2);
+        if (more) read_frags(0, buf ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma16(1);                                              // k-step 3
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+}
+
+// Hand-off of a tile / slab to workgroups on other CUs and XCDs.  The data is stored WRITE-THROUGH (sc1 stores: they leave
+// the XCD's L2 at once), every storing wave drains its stores, the workgroup meets, and the caller's lane 0 then bumps the
+// counters; consumers poll, take ONE agent-scope acquire and read with plain loads (cdna guide G16, the write-through form).
+// The plain-store + release-fence form is not used on purpose: the release (buffer_wbl2) writes back EVERY dirty line of the
+// XCD's L2, i.e. the 128-256 KB tiles that the ~30 other workers of the XCD have just stored as well -- measured: each
+// additional formation chunk cost 160-260 us with it (Q = 8 / 16 against Q = 4), and the chain's own kernels, which do
+// release, took 22-25 us instead of 7-10.
+__device__ __forceinline__ void ff_store_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ff_publish_begin() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
 }
+
+// phases of the diagnostic cycle profile (IPM_FF_PROF=1; tools/ff_debug.py): wave 0 stamps s_memtime at phase boundaries
+enum { FFP_TICKET = 0, FFP_FGEMM, FFP_FSTORE, FFP_TWAIT, FFP_TGEMM, FFP_TBASE, FFP_PWAIT, FFP_PGEMM, FFP_TSTORE, FFP_NF, FFP_NT, FFP_TOTAL };
+#define FF_PROF(slot) do { if (g.prof && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); g.prof[(size_t)blockIdx.x * 16 + (slot)] += t_ - tprev; tprev = t_; } } while (0)
 
 __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     if (g.done && *g.done) return;
@@ -159,57 +361,82 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     // this lane's 32 elements of a 128 x 128 tile (accumulator layout): row = er + i*16 + 4q, col = ec + j*16
     const int er = wm * 64 + fk, ec = wn * 32 + fr;
 
+    long long tprev = g.prof ? __builtin_amdgcn_s_memtime() : 0;
+    const long long tstart = tprev;
     for (;;) {
         if (tid == 0) ticket_s = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned n = ticket_s;
         __syncthreads();                                   // ticket_s is rewritten on the next turn
-        if (n >= (unsigned)g.nitems) return;
+        if (n >= (unsigned)g.nitems) { if (g.prof && tid == 0) g.prof[(size_t)blockIdx.x * 16 + FFP_TOTAL] = __builtin_amdgcn_s_memtime() - tstart; return; }
         const FFItem it = g.items[n];
+        FF_PROF(FFP_TICKET);
         const int ti = it.i, tc = it.c;
         const int tile = ff_tile(ti, tc);
+        if (it.type == FF_F) {
+            // ---- one K-chunk of the formation of the tile PAIR (ti, tc), (ti + 1, tc): raw partial tiles -> slabs (tile, q).
+            //      A half above the diagonal (ti < tc) or below the matrix (ti + 1 == nblk) is computed on a stand-in panel and
+            //      dropped.
+            const bool up = ti >= tc, lo = ti + 1 < g.nblk;
+            const int s0 = it.f.s0, s1 = min(g.nstages, (int)it.f.s1);
+            f64x4 pacc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pacc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+            const int r_up = up ? ti : ti + 1, r_lo = lo ? ti + 1 : ti;
+            if (s1 > s0)
+                ff_gemm_pair(g.A + (int64_t)r_up * 128 * g.lda + (int64_t)s0 * FF_PBK, g.A + (int64_t)r_lo * 128 * g.lda + (int64_t)s0 * FF_PBK,
+                             g.A + (int64_t)tc * 128 * g.lda + (int64_t)s0 * FF_PBK, g.lda, g.d + (int64_t)s0 * FF_PBK, s1 - s0, lds, pacc);
+            FF_PROF(FFP_FGEMM);
+            {
+                const int pm = wave >> 1, pn = wave & 1;              // the pair engine's wave grid: 4 (M) x 2 (N)
+                const int half = pm >> 1;                             // 0: upper tile, 1: lower tile
+                if (half == 0 ? up : lo) {
+                    const int tl = ff_tile(ti + half, tc);
+                    double* sb = g.slab + ((size_t)tl * g.Q + it.q) * (128 * 128) + ((pm & 1) * 64 + fk) * 128 + pn * 64 + fr;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ff_store_wt(sb + (i * 16 + 4 * q) * 128 + j * 16, pacc[i][j][q]);
+                }
+            }
+            ff_publish_begin();
+            if (tid == 0) {
+                if (up) __hip_atomic_fetch_add(g.fcount + ff_tile(ti, tc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lo) __hip_atomic_fetch_add(g.fcount + ff_tile(ti + 1, tc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NF] += 1;
+            }
+            FF_PROF(FFP_FSTORE);
+            continue;
+        }
+
+        // ---- T item: wait for what it needs (one lane, bounded), one acquire
         f64x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-
-        if (it.type == FF_F) {
-            // ---- one K-chunk of the formation of tile (ti, tc): raw partial tile -> slab (tile, q)
-            const int s0 = it.f.s0, s1 = min(g.nstages, (int)it.f.s1);
-            if (s1 > s0)
-                ff_gemm<true, false>(g.A + (int64_t)ti * 128 * g.lda + (int64_t)s0 * FF_BK, g.lda,
-                                     g.A + (int64_t)tc * 128 * g.lda + (int64_t)s0 * FF_BK, g.lda, g.d + (int64_t)s0 * FF_BK,
-                                     s1 - s0, lds, acc, nullptr);
-            double* sb = g.slab + ((size_t)tile * g.Q + it.q) * (128 * 128) + er * 128 + ec;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sb[(i * 16 + 4 * q) * 128 + j * 16] = acc[i][j][q];
-            ff_publish_begin();
-            if (tid == 0) __hip_atomic_fetch_add(g.fcount + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
-        }
-
-        // ---- T item: wait for what it needs (one lane, bounded), one acquire
         const int j0 = it.t.j0, j1 = it.t.j1;
         const int flags = it.t.flags, seq = it.t.seq;
         if (tid == 0) {
-            if (flags & FF_ADD_BASE) ff_wait_ge(g.fcount + tile, (unsigned)g.Q, g.timeout);
-            if (!(flags & FF_INIT)) ff_wait_ge(g.tprog + tile, (unsigned)seq - 1u, g.timeout);
+            if (flags & FF_ADD_BASE) ff_wait_ge(g.fcount + tile, (unsigned)g.Q, g.timeout, g.dbg, n, 1, g.dbg_words);
+            if (!(flags & FF_INIT)) ff_wait_ge(g.tprog + tile, (unsigned)seq - 1u, g.timeout, g.dbg, n, 2, g.dbg_words);
             if (j1 > j0) {
-                ff_wait_ge(g.lfinal + ti, 4u * (unsigned)j1, g.timeout);
-                if (tc != ti) ff_wait_ge(g.lfinal + tc, 4u * (unsigned)j1, g.timeout);
+                ff_wait_ge(g.lfinal + ti, 4u * (unsigned)j1, g.timeout, g.dbg, n, 3, g.dbg_words);
+                if (tc != ti) ff_wait_ge(g.lfinal + tc, 4u * (unsigned)j1, g.timeout, g.dbg, n, 4, g.dbg_words);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        FF_PROF(FFP_TWAIT);
         if (j1 > j0)
-            ff_gemm<false, false>(g.B + (int64_t)ti * 128 * g.ldb + (int64_t)j0 * 128, g.ldb,
-                                  g.B + (int64_t)tc * 128 * g.ldb + (int64_t)j0 * 128, g.ldb, nullptr, (j1 - j0) * (128 / FF_BK), lds, acc, nullptr);
+            ff_gemm_pipe<false>(g.B + (int64_t)ti * 128 * g.ldb + (int64_t)j0 * 128, g.ldb,
+                                g.B + (int64_t)tc * 128 * g.ldb + (int64_t)j0 * 128, g.ldb, nullptr, (j1 - j0) * (128 / FF_BK), lds, acc);
+        FF_PROF(FFP_TGEMM);
         // new tile = [old tile] + [formation slabs, in chunk order] - acc
         double* bt = g.B + ((int64_t)ti * 128 + er) * g.ldb + (int64_t)tc * 128 + ec;
         f64x4 val[4][2];
@@ -252,14 +479,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
                         if (r == c && ti * 128 + r >= g.m) val[i][j][q] = 1.0;
                     }
         }
+        FF_PROF(FFP_TBASE);
         if (flags & FF_PANEL) {
             // L(ti,tc) = tile inv(L(tc,tc))^T: the tile goes back through LDS stage by stage as the P operand
             if (tid == 0) {
-                ff_wait_ge(g.potrfdone + tc, 1u, g.timeout);
+                ff_wait_ge(g.potrfdone + tc, 1u, g.timeout, g.dbg, n, 5, g.dbg_words);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
+            FF_PROF(FFP_PWAIT);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -269,19 +498,22 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) val[i][j] = acc[i][j];
+            FF_PROF(FFP_PGEMM);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16] = val[i][j][q];
+                for (int q = 0; q < 4; ++q) ff_store_wt(bt + (int64_t)(i * 16 + 4 * q) * g.ldb + j * 16, val[i][j][q]);
         ff_publish_begin();
         if (tid == 0) {
             __hip_atomic_store(g.tprog + tile, (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (flags & FF_PANEL) __hip_atomic_fetch_add(g.lfinal + ti, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (flags & FF_SIG_DIAG0) __hip_atomic_fetch_add(g.dready, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NT] += 1;
         }
+        FF_PROF(FFP_TSTORE);
     }
 }
 

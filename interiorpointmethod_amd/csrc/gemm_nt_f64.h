@@ -59,6 +59,7 @@ struct GemmNT {
     const unsigned* wait_on;    // may be null
     unsigned wait_count;
     unsigned* timeout;          // set to 1 when the bounded poll gave up (surfaced as an error by the host)
+    unsigned* dbg; unsigned dbg_tag;   // diagnostic (may be null): the first poll of a call that ran into its bound records {1, tag, 6, target, seen}
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -102,6 +103,10 @@ void gemm_nt_f64_kernel(GemmNT g) {
                 // waiting, or at once when an earlier poll of this call already gave up
                 if (spins > (1u << 22) || ((spins & 1023u) == 1u && g.timeout &&
                                            __hip_atomic_load(g.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (spins > (1u << 22) && g.dbg && __hip_atomic_fetch_add(g.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        g.dbg[1] = g.dbg_tag; g.dbg[2] = 6u; g.dbg[3] = g.wait_count;
+                        g.dbg[4] = __hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (g.timeout) __hip_atomic_store(g.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }

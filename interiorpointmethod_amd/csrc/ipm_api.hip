@@ -136,7 +136,7 @@ struct ipm_handle {
     int ff_enabled = 1;                   // IPM_FUSED_FACTOR=0 disables, =force also below FF_MIN_NBLK blocks (tests)
     int ff_min_nblk = 16, ff_max_nblk = 40;   // beyond ~48 blocks the two-level serial schedule is the measured default (IPM_FF_MAX_NBLK)
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
-    int ff_workers = 0;                   // workgroups of the persistent launch (IPM_FF_WORKERS; default: CUs - 8)
+    int ff_workers = 0;                   // workgroups of the persistent launch (IPM_FF_WORKERS; default: 7/8 of the CUs)
     bool ff_built = false, ff_last = false;
     FFSchedule ff_sched;
     FFItem* d_ff_items = nullptr;
@@ -145,6 +145,7 @@ struct ipm_handle {
     double* ff_slab = nullptr;            // [ntile][Q][128*128]
     double* ff_part = nullptr;            // [256] block maxima of ff_maxdiag_kernel
     hipEvent_t ev_ffjoin = nullptr;
+    long long* ff_prof = nullptr;         // IPM_FF_PROF=1: [workers][16] cycle profile of the persistent launch (accumulates)
     const int* fdone = nullptr;           // `done` word the formation / factorization kernels test (null: Scalars::done; the overlapped
                                           // path points it at the per-iteration latch Scalars::done_f)
     // Tile envelope (skyline) of A A^T for sparse handles, from the structure of A in the caller's row order:
@@ -539,6 +540,17 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
 extern "C" int ipm_destroy(ipm_handle* h) {
     if (!h) return IPM_OK;
     (void)hipSetDevice(h->device);
+    if (h->ff_prof) {          // diagnostic: where the workers' cycles went (sum over the handle's fused launches)
+        (void)hipDeviceSynchronize();
+        std::vector<long long> P(16 * (size_t)h->ff_workers);
+        (void)hipMemcpy(P.data(), h->ff_prof, sizeof(long long) * P.size(), hipMemcpyDeviceToHost);
+        double tot[16] = {0};
+        for (int w = 0; w < h->ff_workers; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)P[(size_t)w * 16 + k];
+        static const char* nm[] = {"ticket", "F gemm", "F store+publish", "T wait", "T gemm", "T base+combine", "panel wait", "panel gemm", "T store+publish"};
+        double sum = 0; for (int k = 0; k < 9; ++k) sum += tot[k];
+        fprintf(stderr, "[ff prof] %d workers, F items %.0f, T items %.0f, cycles per worker in the launches %.3g (sum of phases %.3g)\n", h->ff_workers, tot[FFP_NF], tot[FFP_NT], tot[FFP_TOTAL] / h->ff_workers, sum / h->ff_workers);
+        for (int k = 0; k < 9; ++k) fprintf(stderr, "   %-18s %6.2f %%\n", nm[k], 100.0 * tot[k] / sum);
+    }
     if (h->counted) g_live[h->device].fetch_sub(1, std::memory_order_acq_rel);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -558,7 +570,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
     for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
-                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part})
+                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof})
         dev_free(h->device, h->stream, p);
     free_sparse_factor(h);
     for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
@@ -1323,7 +1335,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         pd.inv = h->invD + (int64_t)k * NB * NB;
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
-        pd.wait_on = nullptr; pd.wait_count = 0; pd.signal = nullptr; pd.timeout = nullptr;
+        pd.wait_on = nullptr; pd.wait_count = 0; pd.signal = nullptr; pd.timeout = nullptr; pd.dbg = nullptr; pd.dbg_tag = 0;
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
             hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
@@ -1460,7 +1472,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
 // device to themselves; a recovered poll time-out clears flag_sync and with it this path, for good)
 static bool ff_ok(const ipm_handle* h) {
     if (!h->ff_enabled || h->sparse || h->lookahead == 0 || h->stream2 == nullptr || h->flag_sync == 0) return false;
-    if (h->nblk < h->ff_min_nblk || h->nblk > std::min(h->ff_max_nblk, FF_MAX_NBLK) || h->np % FF_BK) return false;
+    if (h->nblk < h->ff_min_nblk || h->nblk > std::min(h->ff_max_nblk, FF_MAX_NBLK) || h->np % FF_PBK) return false;
     return h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
 }
 
@@ -1470,10 +1482,15 @@ static int ff_build(ipm_handle* h) {
     if (h->ff_workers <= 0) {
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
-        // one workgroup per CU (136 KB of LDS each) on all CUs but eight: those stay empty for the pivot chain's kernels
-        h->ff_workers = std::max(8, prop.multiProcessorCount - 8);
+        // One workgroup per CU (136 KB of LDS, all of a CU's registers) on all CUs but ONE PER SHADER ENGINE: 7 of the 8 CUs
+        // of each of the 32 engines on MI355X = 224 workers; the 32 CUs left empty host the pivot chain's kernels and whatever
+        // the residual stream launches meanwhile.  Measured (2048 x 4100, 16 blocks, tools/ff_debug.py): with 248 / 247
+        // workers a workgroup of a chain kernel can wait forever (always, resp. usually: the launch then ends through its spin
+        // bounds), with 240 / 232 in 1 of 6 / 5 of 8 runs, with 224 never -- the dispatcher deals workgroups to XCDs and
+        // engines round-robin without regard to where the free CUs are, so EVERY engine needs a free one.
+        h->ff_workers = std::max(8, prop.multiProcessorCount - prop.multiProcessorCount / 8);
     }
-    const int nstages = (int)(h->np / FF_BK);
+    const int nstages = (int)(h->np / FF_PBK);               // BK = 16 stages of the pair engine
     const int Q = std::max(1, std::min(h->ff_q, nstages));
     h->ff_q = Q;
     FFModel M;
@@ -1484,7 +1501,11 @@ static int ff_build(ipm_handle* h) {
         std::vector<int> fcnt(ntile, 0), base(ntile, 0), applied(ntile, 0), paneled(ntile, 0);
         for (const FFItem& it : h->ff_sched.items) {
             const size_t t = (size_t)ff_tile(it.i, it.c);
-            if (it.type == FF_F) { fcnt[t]++; continue; }
+            if (it.type == FF_F) {
+                if (it.c <= it.i) fcnt[t]++;
+                if (it.i + 1 < h->nblk) fcnt[(size_t)ff_tile(it.i + 1, it.c)]++;
+                continue;
+            }
             if (it.t.j0 != applied[t]) return fail(h, IPM_ERR_INVALID_ARG, "fused factor: internal error (column order of tile %d,%d)", it.i, it.c);
             applied[t] = it.t.j1;
             if (it.t.flags & FF_ADD_BASE) base[t]++;
@@ -1501,9 +1522,13 @@ static int ff_build(ipm_handle* h) {
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * nit));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, h->ff_sched.items.data(), sizeof(FFItem) * nit, hipMemcpyHostToDevice, h->stream));
     h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk;
-    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * h->ff_flag_words));
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * 2 * h->ff_flag_words));     // live words + diagnostic snapshot
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)Q * 128 * 128));
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_part, sizeof(double) * 256));
+    if (getenv("IPM_FF_PROF")) {
+        HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_prof, sizeof(long long) * 16 * (size_t)h->ff_workers));
+        HIP_TRY(h, hipMemsetAsync(h->ff_prof, 0, sizeof(long long) * 16 * (size_t)h->ff_workers, h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ff_built = true;
     return IPM_OK;
@@ -1520,22 +1545,26 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     const int* done = h->fdone ? h->fdone : &h->sc->done;
     hipStream_t sw = h->stream, sm = h->stream2;
     unsigned* F = h->d_ff_flags;
-    unsigned *ticket = F, *mticket = F + 16, *fcount = F + 32, *tprog = fcount + ntile, *lfinal = tprog + ntile, *dready = lfinal + nblk,
+    unsigned *ticket = F, *mticket = F + 16, *dbg = F + 24, *fcount = F + 32, *tprog = fcount + ntile, *lfinal = tprog + ntile, *dready = lfinal + nblk,
              *potrfdone = dready + nblk;
     unsigned* timeout = h->d_flags + 2 * (size_t)nblk;
     HIP_TRY(h, hipMemsetAsync(F, 0, sizeof(unsigned) * h->ff_flag_words, sw));
-    // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end here)
-    hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sw, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
-                       &h->sc->maxdiag, done);
     HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
     HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
+    // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
+    // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
+    // formation chunks -- the first diagonal tile is not ready before those are done anyway
+    hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
+                       &h->sc->maxdiag, done);
     FFArgs a;
     memset(&a, 0, sizeof a);
     a.A = h->A; a.lda = h->np; a.d = h->d; a.B = h->B; a.ldb = h->mp; a.invD = h->invD; a.slab = h->ff_slab;
     a.items = h->d_ff_items; a.nitems = (int)h->ff_sched.items.size();
     a.ticket = ticket; a.fcount = fcount; a.tprog = tprog; a.lfinal = lfinal; a.dready = dready; a.potrfdone = potrfdone;
-    a.timeout = timeout; a.done = done;
-    a.nblk = nblk; a.Q = h->ff_q; a.nstages = (int)(h->np / FF_BK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
+    a.timeout = timeout; a.dbg = dbg; a.done = done;
+    { static const bool dbg_on = getenv("IPM_FF_DEBUG") != nullptr; a.dbg_words = dbg_on ? (unsigned)h->ff_flag_words : 0u; }
+    a.prof = h->ff_prof;
+    a.nblk = nblk; a.Q = h->ff_q; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
     hipLaunchKernelGGL(form_factor_kernel, dim3((unsigned)h->ff_workers), dim3(FF_THREADS), 0, sw, a);
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], sw));
@@ -1547,7 +1576,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         pd.inv = h->invD + (int64_t)k * NB * NB;
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
-        pd.wait_on = dready + k; pd.wait_count = 10; pd.signal = potrfdone + k; pd.timeout = timeout;
+        pd.wait_on = dready + k; pd.wait_count = 10; pd.signal = potrfdone + k; pd.timeout = timeout; pd.dbg = dbg; pd.dbg_tag = (unsigned)k;
         hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         ++h->n_counter_steps;
         if (k == ginv_step) {
@@ -1566,6 +1595,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         tc.alpha = 1.0; tc.beta = 0.0; tc.lower = 0; tc.unit_diag_from = -1; tc.done = done;
         tc.wait_on = tprog + ff_tile(k + 1, k); tc.wait_count = (unsigned)h->ff_sched.tile_items[(size_t)ff_tile(k + 1, k)];
         tc.signal = lfinal + (k + 1); tc.timeout = timeout;         // four workgroups, one count each: 4 = one final tile
+        tc.dbg = dbg; tc.dbg_tag = 1000u + (unsigned)k;
         HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));
         GemmNT uc = gemm_defaults();                                // tile (k+1,k+1) -= L(k+1,k) L(k+1,k)^T
         uc.tile_order = nullptr; uc.batch = 1; uc.batch2 = 1;
@@ -1574,6 +1604,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         uc.alpha = -1.0; uc.beta = 1.0; uc.lower = 1; uc.unit_diag_from = -1; uc.done = done;
         uc.wait_on = tprog + ff_tile(k + 1, k + 1); uc.wait_count = (unsigned)h->ff_sched.tile_items[(size_t)ff_tile(k + 1, k + 1)];
         uc.signal = dready + (k + 1); uc.timeout = timeout;         // ten 32 x 32 sub-tiles, one count each
+        uc.dbg = dbg; uc.dbg_tag = 2000u + (unsigned)k;
         HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));
     }
     HIP_TRY(h, hipEventRecord(h->ev_ffjoin, sm));
@@ -1589,7 +1620,8 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     static_assert(sizeof(FFItem) == 8, "work item layout");
     FFSchedule S;
     FFModel M;
-    M.f_stages = std::max(1, 256 / q); M.nstages = 256;       // K = 8192 (the headline size's formation)
+    M.f_stages = std::max(1, 512 / q); M.nstages = 512;       // K = 8192 (the headline size's formation), BK = 16 stages
+    if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) { M.nstages = std::max(q, atoi(e)); M.f_stages = (M.nstages + q - 1) / q; }
     ff_build_schedule(nblk, q, workers, M, S);
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));
@@ -1819,6 +1851,19 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         const int rstep = h->residual_step >= 0 ? std::min(h->residual_step, h->nblk - 1) : h->nblk * 13 / 16;
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
         const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
+        static const bool ff_overlap = !(getenv("IPM_FF_OVERLAP") && atoi(getenv("IPM_FF_OVERLAP")) == 0);
+        if (fused && !ff_overlap) {
+            // experiment: no residual-stream work beside the fused launch -- residuals, group inverses after it, in stream order
+            if ((rc = enqueue_form_factor(h, ev, -1, -1))) return rc;
+            h->fdone = nullptr;
+            if ((rc = enqueue_residuals(h))) return rc;
+            launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);
+            if ((rc = enqueue_group_inverses(h, 0, nG, nullptr))) return rc;
+            if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;
+            if ((rc = enqueue_corrector(h, nullptr))) return rc;
+            if ((rc = enqueue_update(h))) return rc;
+            return IPM_OK;
+        }
         if (fused) { if ((rc = enqueue_form_factor(h, ev, rstep, gstep))) return rc; }
         else if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
         h->fdone = nullptr;
@@ -1872,6 +1917,40 @@ static int read_scalars(ipm_handle* h, bool* timed_out = nullptr) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (tmo) {
         if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));               // the bulk stream may still be draining
+        if (h->ff_built && h->ff_last && getenv("IPM_FF_DEBUG")) {
+            // diagnostic: where did the fused launch stop?  (hand-off words of the LAST factorization of the call)
+            std::vector<unsigned> F(h->ff_flag_words);
+            (void)hipMemcpy(F.data(), h->d_ff_flags, sizeof(unsigned) * F.size(), hipMemcpyDeviceToHost);
+            if (F[24] && F[26] < 6) {           // a worker wait gave up first: show the snapshot it took instead of the final state
+                std::vector<unsigned> S(h->ff_flag_words);
+                (void)hipMemcpy(S.data(), h->d_ff_flags + h->ff_flag_words, sizeof(unsigned) * S.size(), hipMemcpyDeviceToHost);
+                for (size_t w = 0; w < F.size(); ++w) if (w < 24 || w >= 32) F[w] = S[w];
+                fprintf(stderr, "[ff debug] (snapshot taken by the first wait that gave up)\n");
+            }
+            const int nb = h->nblk; const size_t nt = (size_t)nb * (nb + 1) / 2;
+            const unsigned *fc = F.data() + 32, *tp = fc + nt, *lf = tp + nt, *dr = lf + nb, *pd = dr + nb;
+            fprintf(stderr, "[ff debug] ticket %u of %zu items; first worker wait that gave up: count %u item %u kind %u target %u seen %u\n", F[0],
+                    h->ff_sched.items.size(), F[24], F[25], F[26], F[27], F[28]);
+            if (F[24] && F[26] < 6 && F[25] < h->ff_sched.items.size()) {
+                const FFItem& it = h->ff_sched.items[F[25]];
+                fprintf(stderr, "  that item: T(%d,%d)[%d,%d) flags %d seq %d\n", it.i, it.c, it.t.j0, it.t.j1, it.t.flags, it.t.seq);
+            }
+            fprintf(stderr, "  potrfdone:");
+            for (int k = 0; k < nb; ++k) fprintf(stderr, " %u", pd[k]);
+            fprintf(stderr, "\n  dready:");
+            for (int k = 0; k < nb; ++k) fprintf(stderr, " %u", dr[k]);
+            fprintf(stderr, "\n  lfinal:");
+            for (int k = 0; k < nb; ++k) fprintf(stderr, " %u", lf[k]);
+            fprintf(stderr, "\n  incomplete tiles (i,c: fcount tprog/expected):");
+            int shown = 0;
+            for (int i = 0; i < nb; ++i)
+                for (int c = 0; c <= i; ++c) {
+                    const size_t t = (size_t)ff_tile(i, c);
+                    if ((fc[t] != (unsigned)h->ff_q || tp[t] != (unsigned)h->ff_sched.tile_items[t]) && shown++ < 24)
+                        fprintf(stderr, " (%d,%d: %u %u/%d)", i, c, fc[t], tp[t], h->ff_sched.tile_items[t]);
+                }
+            fprintf(stderr, "\n");
+        }
         HIP_TRY(h, hipMemsetAsync(word, 0, sizeof(unsigned), h->stream));
         if (!timed_out) return fail(h, IPM_ERR_HIP, "a device-side hand-off poll timed out (persistent solve)");
     }

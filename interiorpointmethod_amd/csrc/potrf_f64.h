@@ -50,6 +50,7 @@ struct PotrfDiag {
     const unsigned* wait_on; unsigned wait_count;
     unsigned* signal;
     unsigned* timeout;
+    unsigned* dbg; unsigned dbg_tag;   // diagnostic (may be null): see GemmNT::dbg; kind 7
 };
 
 // sqrt(p) and 1/sqrt(p) from v_rsq_f64 (about 23 good bits) and one Halley step
@@ -396,6 +397,10 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
                 ++spins;
                 if (spins > (1u << 22) || ((spins & 1023u) == 1u && a.timeout &&
                                            __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (spins > (1u << 22) && a.dbg && __hip_atomic_fetch_add(a.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        a.dbg[1] = a.dbg_tag; a.dbg[2] = 7u; a.dbg[3] = a.wait_count;
+                        a.dbg[4] = __hip_atomic_load(a.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (a.timeout) __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }

@@ -26,13 +26,18 @@
 
 #include "ff_schedule.h"
 #include "gemm_nt_f64.h"
+#include "potrf_f64.h"
 
 namespace ipm {
 
 constexpr int FF_THREADS = 512;
 constexpr int FF_BK = 32, FF_LDT = FF_BK + 2;
 constexpr int FF_OP = 128 * FF_LDT;                    // doubles of one operand tile of one stage
-constexpr int FF_LDS_DOUBLES = 4 * FF_OP;              // P, Q x two buffers: 139,264 B -> one workgroup per CU
+constexpr int FF_WLD = 130;                            // leading dimension of the chain role's diagonal-block workspace (= WLD of potrf_f64.h)
+constexpr int FF_CHAIN_STG = 128 * 18;                 // chain role: one 128 x 16 slice of the panel tile (rows padded to 18)
+constexpr int FF_LDS_WORKER = 4 * FF_OP;               // workers: P, Q x two buffers = 139,264 B
+constexpr int FF_LDS_CHAIN = 128 * FF_WLD + 128 + FF_CHAIN_STG;   // chain: W + 1 / diag(L) + slice = 152,576 B
+constexpr int FF_LDS_DOUBLES = FF_LDS_CHAIN > FF_LDS_WORKER ? FF_LDS_CHAIN : FF_LDS_WORKER;   // one workgroup per CU either way
 
 struct FFArgs {
     const double* A; int64_t lda;      // [mp][lda] row-major, zero padded
@@ -51,9 +56,18 @@ struct FFArgs {
     unsigned* dbg;                     // [8] diagnostic (first wait that gave up), may be null
     unsigned dbg_words;                // hand-off words to snapshot on that occasion (0: none)
     long long* prof;                   // diagnostic (may be null): [workgroups][16] cycles per phase (s_memtime), see FF_PROF
+    long long* cprof;                  // diagnostic (may be null): chain role, [nblk][4] s_memtime at: inputs of P ready, P done, D done, potrf done
     const int* done;
     int nblk, Q, nstages, fstages;     // nstages = K / 16 of the formation (BK = 16 stages of the pair engine), fstages = stages per chunk
     int m;                             // true rows: padding rows get a unit diagonal
+    // chain role (workgroup 0 of the launch when chain_in_kernel != 0): the pivot chain without kernel launches
+    int chain_in_kernel;
+    const int* tile_items;             // [ntile] T items per tile (what the chain waits for on its tiles)
+    unsigned long long* maxbits;       // max diag(B) over the true rows as the bit pattern of a non-negative double (FF_D items)
+    unsigned* dcount;                  // FF_D items complete
+    double* maxdiag_out;               // Scalars::maxdiag (for the record)
+    double eps, big, shift_rel;        // pivot guard / Tikhonov shift, as PotrfDiag
+    int* fixed;                        // guarded pivots (accumulates)
 };
 
 // dbg (optional, 8 words, zeroed per launch): the FIRST wait of the launch that gave up records {1, item, kind, target, seen}
@@ -346,6 +360,184 @@ __device__ __forceinline__ void ff_publish_begin() {
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// CHAIN role: the pivot chain of the blocked Cholesky inside the persistent launch (workgroup 0), instead of three kernel
+// launches per step on a second stream.  Per step k:
+//   P   L(k,k-1) = tile(k,k-1) inv(L(k-1,k-1))^T   -- the inverse is still in the LDS workspace W of the previous potrf
+//                 (upper triangle, shifted one column: potrf_f64.h), the tile streams through a 128 x 16 slice buffer;
+//                 the result goes to memory (write-through) and into W, which the inverse no longer needs;
+//   D   tile(k,k) -= L(k,k-1) L(k,k-1)^T           -- both operands from W, the tile from memory (the workers applied the
+//                 columns before k-1), the result back into W: it never travels through memory;
+//   potrf_lds(W)  -- the 128 x 128 guarded Cholesky of potrf_f64.h -- then L(k,k) and inv(L(k,k)) to memory, potrfdone[k].
+// No launch boundaries, no dispatcher between the steps, and no CU has to be kept free for it: every other workgroup of the
+// launch is a worker.  Hand-offs with the workers are the same counters the multi-launch chain used.
+__device__ __attribute__((noinline)) void ff_chain_role(const FFArgs& g, double* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int er = wm * 64 + fk, ec = wn * 32 + fr;          // this lane's elements of a tile: row er + 16 i + 4 q, col ec + 16 j
+    double* W = lds;                                         // [128][FF_WLD]
+    double* dinv_s = lds + 128 * FF_WLD;                     // [128]
+    double* stg = dinv_s + 128;                              // [128][18]
+    double thresh = 0.0, maxdiag = 0.0;
+#define FF_CSTAMP(slot) do { if (g.cprof && tid == 0) g.cprof[(size_t)k * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+    for (int k = 0; k < g.nblk; ++k) {
+        double* Bkk = g.B + (int64_t)k * 128 * (g.ldb + 1);
+        if (k == 0) {
+            if (tid == 0) {
+                ff_wait_ge(g.dcount, (unsigned)g.nblk, g.timeout, g.dbg, 9000u, 8, g.dbg_words);
+                ff_wait_ge(g.dready, 10u, g.timeout, g.dbg, 9000u, 9, g.dbg_words);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            FF_CSTAMP(0);
+            maxdiag = __longlong_as_double((long long)__hip_atomic_load(g.maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            thresh = g.eps * maxdiag;
+            if (tid == 0) *g.maxdiag_out = maxdiag;
+            // tile (0,0): rows complete up to the end of their 16-wide diagonal tile (what potrf_lds reads)
+            f64x2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = tid + u * FF_THREADS, i = idx >> 6, c2 = (idx & 63) * 2;
+                v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(Bkk + (int64_t)i * g.ldb + c2) : (f64x2){0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = tid + u * FF_THREADS, i = idx >> 6, c2 = (idx & 63) * 2;
+                if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * FF_WLD + c2]) = v[u];
+            }
+        } else {
+            // ---- P: L(k,k-1) = tile(k,k-1) X^T, X = inv(L(k-1,k-1)): X[c][kk] (kk <= c) sits at W[kk * FF_WLD + c + 1]
+            double* tkk1 = g.B + (int64_t)k * 128 * g.ldb + (int64_t)(k - 1) * 128;
+            if (tid == 0) {
+                ff_wait_ge(g.tprog + ff_tile(k, k - 1), (unsigned)g.tile_items[ff_tile(k, k - 1)], g.timeout, g.dbg, 9000u + k, 6, g.dbg_words);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            FF_CSTAMP(0);
+            f64x4 pl[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pl[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+            // slice staging: thread -> 16-byte chunk sc (of 8) of rows sr and sr + 64
+            const int sc = tid & 7, sr = tid >> 3;
+            f64x2 sv[2];
+            sv[0] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)sr * g.ldb + sc * 2);
+            sv[1] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)(sr + 64) * g.ldb + sc * 2);
+            for (int sl = 0; sl < 8; ++sl) {
+                *reinterpret_cast<f64x2*>(stg + sr * 18 + sc * 2) = sv[0];
+                *reinterpret_cast<f64x2*>(stg + (sr + 64) * 18 + sc * 2) = sv[1];
+                __syncthreads();
+                if (sl + 1 < 8) {
+                    sv[0] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)sr * g.ldb + (sl + 1) * 16 + sc * 2);
+                    sv[1] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)(sr + 64) * g.ldb + (sl + 1) * 16 + sc * 2);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int kidx = sl * 16 + kk * 4 + fk;
+                    double a[4], b[2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = stg[(wm * 64 + i * 16 + fr) * 18 + kk * 4 + fk];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { const int c = wn * 32 + j * 16 + fr; b[j] = (kidx <= c) ? W[kidx * FF_WLD + c + 1] : 0.0; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) pl[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], pl[i][j], 0, 0, 0);
+                }
+                __syncthreads();                              // the slice buffer is rewritten next
+            }
+            // L(k,k-1) to memory (write-through) and into W (the inverse is dead: every wave passed the barrier above)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = er + i * 16 + 4 * q, c = ec + j * 16;
+                        ff_store_wt(tkk1 + (int64_t)r * g.ldb + c, pl[i][j][q]);
+                        W[r * FF_WLD + c] = pl[i][j][q];
+                    }
+            ff_publish_begin();
+            FF_CSTAMP(1);
+            if (tid == 0) {
+                __hip_atomic_fetch_add(g.lfinal + k, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ---- D needs the diagonal tile with every column before k-1 applied
+                ff_wait_ge(g.tprog + ff_tile(k, k), (unsigned)g.tile_items[ff_tile(k, k)], g.timeout, g.dbg, 9000u + k, 7, g.dbg_words);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            f64x4 dd[4][2], tv[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    dd[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tv[i][j][q] = Bkk[(int64_t)(er + i * 16 + 4 * q) * g.ldb + ec + j * 16];
+                }
+            for (int kk = 0; kk < 32; ++kk) {
+                double a[4], b[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = W[(wm * 64 + i * 16 + fr) * FF_WLD + kk * 4 + fk];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = W[(wn * 32 + j * 16 + fr) * FF_WLD + kk * 4 + fk];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) dd[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], dd[i][j], 0, 0, 0);
+            }
+            __syncthreads();                                  // every read of L(k,k-1) in W is done
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) W[(er + i * 16 + 4 * q) * FF_WLD + ec + j * 16] = tv[i][j][q] - dd[i][j][q];
+        }
+        if (g.shift_rel != 0.0) {
+            __syncthreads();
+            if (tid < 128) W[tid * FF_WLD + tid] += g.shift_rel * maxdiag;
+        }
+        __syncthreads();
+        FF_CSTAMP(2);
+        // ---- the diagonal block itself; L and the first 112 rows of the inverse go out under the assembly of the last inverse row
+        double* inv = const_cast<double*>(g.invD) + (int64_t)k * 128 * 128;
+        auto write_rows = [&](int u0, int u1, bool want_l, int inv_lo, int inv_hi) {
+            for (int u = u0; u < u1; ++u) {
+                const int idx = tid + u * FF_THREADS, i = idx >> 6, j = (idx & 63) * 2;
+                if (j <= i) {
+                    const bool wi = i >= inv_lo && i < inv_hi;
+                    if (j + 1 <= i) {
+                        if (want_l) *reinterpret_cast<f64x2*>(Bkk + (int64_t)i * g.ldb + j) = (f64x2){W[i * FF_WLD + j], W[i * FF_WLD + j + 1]};
+                        if (wi) *reinterpret_cast<f64x2*>(inv + i * 128 + j) = (f64x2){W[j * FF_WLD + i + 1], W[(j + 1) * FF_WLD + i + 1]};
+                    } else {
+                        if (want_l) Bkk[(int64_t)i * g.ldb + j] = W[i * FF_WLD + j];
+                        if (wi) inv[i * 128 + j] = W[j * FF_WLD + i + 1];
+                    }
+                }
+            }
+        };
+        const int nfix = potrf_lds<false>(W, dinv_s, 8, thresh, g.big, nullptr, [&]() { write_rows(0, 16, true, 0, 112); });
+        write_rows(14, 16, false, 112, 128);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (nfix) atomicAdd(g.fixed, nfix);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (plain 16-byte stores above; this XCD's L2 holds little else dirty)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(const_cast<unsigned*>(g.potrfdone) + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        FF_CSTAMP(3);
+    }
+#undef FF_CSTAMP
+}
+
 // phases of the diagnostic cycle profile (IPM_FF_PROF=1; tools/ff_debug.py): wave 0 stamps s_memtime at phase boundaries
 enum { FFP_TICKET = 0, FFP_FGEMM, FFP_FSTORE, FFP_TWAIT, FFP_TGEMM, FFP_TBASE, FFP_PWAIT, FFP_PGEMM, FFP_TSTORE, FFP_NF, FFP_NT, FFP_TOTAL };
 #define FF_PROF(slot) do { if (g.prof && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); g.prof[(size_t)blockIdx.x * 16 + (slot)] += t_ - tprev; tprev = t_; } } while (0)
@@ -361,6 +553,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     // this lane's 32 elements of a 128 x 128 tile (accumulator layout): row = er + i*16 + 4q, col = ec + j*16
     const int er = wm * 64 + fk, ec = wn * 32 + fr;
 
+    if (g.chain_in_kernel && blockIdx.x == 0) { ff_chain_role(g, lds); return; }
     long long tprev = g.prof ? __builtin_amdgcn_s_memtime() : 0;
     const long long tstart = tprev;
     for (;;) {
@@ -373,6 +566,30 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         FF_PROF(FFP_TICKET);
         const int ti = it.i, tc = it.c;
         const int tile = ff_tile(ti, tc);
+        if (it.type == FF_D) {
+            // ---- diag(B) of the true rows of block ti straight from A and d -> running maximum (the pivot guard's scale): one
+            //      wave per row, 16 rows per wave; max of non-negative doubles through their bit patterns (order independent)
+            double mx = 0.0;
+            for (int rr = wave; rr < 128; rr += 8) {
+                const int row = ti * 128 + rr;
+                if (row >= g.m) break;
+                const double* a = g.A + (int64_t)row * g.lda;
+                double sacc = 0.0;
+                for (int kq = lane * 2; kq < g.nstages * FF_PBK; kq += 128) {
+                    const f64x2 va = *reinterpret_cast<const f64x2*>(a + kq);
+                    const f64x2 vd = *reinterpret_cast<const f64x2*>(g.d + kq);
+                    sacc = __builtin_fma(va.x * va.x, vd.x, sacc);
+                    sacc = __builtin_fma(va.y * va.y, vd.y, sacc);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+                mx = (sacc > mx) ? sacc : mx;            // NaN never wins
+            }
+            if (lane == 0) atomicMax(g.maxbits, (unsigned long long)__double_as_longlong(mx));
+            ff_publish_begin();
+            if (tid == 0) __hip_atomic_fetch_add(g.dcount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         if (it.type == FF_F) {
             // ---- one K-chunk of the formation of the tile PAIR (ti, tc), (ti + 1, tc): raw partial tiles -> slabs (tile, q).
             //      A half above the diagonal (ti < tc) or below the matrix (ti + 1 == nblk) is computed on a stand-in panel and

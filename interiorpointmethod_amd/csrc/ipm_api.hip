@@ -136,7 +136,10 @@ struct ipm_handle {
     int ff_enabled = 1;                   // IPM_FUSED_FACTOR=0 disables, =force also below FF_MIN_NBLK blocks (tests)
     int ff_min_nblk = 16, ff_max_nblk = 40;   // beyond ~48 blocks the two-level serial schedule is the measured default (IPM_FF_MAX_NBLK)
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
-    int ff_workers = 0;                   // workgroups of the persistent launch (IPM_FF_WORKERS; default: 7/8 of the CUs)
+    int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: all CUs but one with
+                                          // the chain in the kernel, 7/8 of the CUs with the chain as launches on a second stream)
+    int ff_chain_in_kernel = 1;           // IPM_FF_CHAIN=launches: the pivot chain as three kernel launches per step (round-3 first version)
+    int* d_ff_tile_items = nullptr;
     bool ff_built = false, ff_last = false;
     FFSchedule ff_sched;
     FFItem* d_ff_items = nullptr;
@@ -514,6 +517,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; } else h->ff_enabled = atoi(e); }
     if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
+    if (const char* e = getenv("IPM_FF_CHAIN")) h->ff_chain_in_kernel = strcmp(e, "launches") != 0;
     if (const char* e = getenv("IPM_FF_Q")) h->ff_q = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("IPM_FF_WORKERS")) h->ff_workers = std::max(1, atoi(e));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_ffjoin, hipEventDisableTiming));
@@ -542,10 +546,17 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->ff_prof) {          // diagnostic: where the workers' cycles went (sum over the handle's fused launches)
         (void)hipDeviceSynchronize();
-        std::vector<long long> P(16 * (size_t)h->ff_workers);
+        std::vector<long long> P(16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk);
         (void)hipMemcpy(P.data(), h->ff_prof, sizeof(long long) * P.size(), hipMemcpyDeviceToHost);
         double tot[16] = {0};
-        for (int w = 0; w < h->ff_workers; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)P[(size_t)w * 16 + k];
+        for (int w = 0; w <= h->ff_workers; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)P[(size_t)w * 16 + k];
+        if (h->ff_chain_in_kernel) {
+            const long long* C = P.data() + 16 * ((size_t)h->ff_workers + 1);
+            fprintf(stderr, "[ff prof] chain role, last launch, cycles per step (wait for the panel tile | P | wait + D | potrf + write):\n");
+            for (int k = 1; k < h->nblk; ++k)
+                fprintf(stderr, "   step %2d: %7lld | %6lld | %6lld | %6lld\n", k, C[(size_t)k * 4] - C[(size_t)(k - 1) * 4 + 3], C[(size_t)k * 4 + 1] - C[(size_t)k * 4], C[(size_t)k * 4 + 2] - C[(size_t)k * 4 + 1], C[(size_t)k * 4 + 3] - C[(size_t)k * 4 + 2]);
+            fprintf(stderr, "   first block factored %lld cycles after the launch's first stamp; whole chain %lld cycles\n", C[3] - C[0], C[(size_t)(h->nblk - 1) * 4 + 3] - C[0]);
+        }
         static const char* nm[] = {"ticket", "F gemm", "F store+publish", "T wait", "T gemm", "T base+combine", "panel wait", "panel gemm", "T store+publish"};
         double sum = 0; for (int k = 0; k < 9; ++k) sum += tot[k];
         fprintf(stderr, "[ff prof] %d workers, F items %.0f, T items %.0f, cycles per worker in the launches %.3g (sum of phases %.3g)\n", h->ff_workers, tot[FFP_NF], tot[FFP_NT], tot[FFP_TOTAL] / h->ff_workers, sum / h->ff_workers);
@@ -570,7 +581,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
     for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
-                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof})
+                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof, (void*)h->d_ff_tile_items})
         dev_free(h->device, h->stream, p);
     free_sparse_factor(h);
     for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
@@ -1482,25 +1493,29 @@ static int ff_build(ipm_handle* h) {
     if (h->ff_workers <= 0) {
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
-        // One workgroup per CU (136 KB of LDS, all of a CU's registers) on all CUs but ONE PER SHADER ENGINE: 7 of the 8 CUs
-        // of each of the 32 engines on MI355X = 224 workers; the 32 CUs left empty host the pivot chain's kernels and whatever
-        // the residual stream launches meanwhile.  Measured (2048 x 4100, 16 blocks, tools/ff_debug.py): with 248 / 247
-        // workers a workgroup of a chain kernel can wait forever (always, resp. usually: the launch then ends through its spin
-        // bounds), with 240 / 232 in 1 of 6 / 5 of 8 runs, with 224 never -- the dispatcher deals workgroups to XCDs and
-        // engines round-robin without regard to where the free CUs are, so EVERY engine needs a free one.
-        h->ff_workers = std::max(8, prop.multiProcessorCount - prop.multiProcessorCount / 8);
+        // Chain in the kernel (default): one workgroup per CU on EVERY CU, workgroup 0 runs the pivot chain, the rest work.
+        // Chain as launches on the second stream: one workgroup per CU on all CUs but ONE PER SHADER ENGINE -- 7 of the 8
+        // CUs of each of the 32 engines on MI355X = 224 workers; the 32 CUs left empty host the chain's kernels.  Measured
+        // (2048 x 4100, 16 blocks, tools/ff_debug.py): with 248 / 247 workers a workgroup of a chain kernel can wait forever
+        // (always, resp. usually: the launch then ends through its spin bounds), with 240 / 232 in 1 of 6 / 5 of 8 runs, with
+        // 224 never -- the dispatcher deals workgroups to XCDs and engines round-robin without regard to where the free CUs
+        // are, so EVERY engine needs a free one.  That is what the chain-in-kernel form does away with.
+        h->ff_workers = h->ff_chain_in_kernel ? std::max(1, prop.multiProcessorCount - 1)
+                                              : std::max(8, prop.multiProcessorCount - prop.multiProcessorCount / 8);
     }
     const int nstages = (int)(h->np / FF_PBK);               // BK = 16 stages of the pair engine
     const int Q = std::max(1, std::min(h->ff_q, nstages));
     h->ff_q = Q;
     FFModel M;
     M.f_stages = (nstages + Q - 1) / Q; M.nstages = nstages;
+    if (h->ff_chain_in_kernel) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
     ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched);
     const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
     {   // every tile complete?  (an incomplete list would be an internal error of the scheduler, never a reason to hang a GPU)
         std::vector<int> fcnt(ntile, 0), base(ntile, 0), applied(ntile, 0), paneled(ntile, 0);
         for (const FFItem& it : h->ff_sched.items) {
             const size_t t = (size_t)ff_tile(it.i, it.c);
+            if (it.type == FF_D) continue;
             if (it.type == FF_F) {
                 if (it.c <= it.i) fcnt[t]++;
                 if (it.i + 1 < h->nblk) fcnt[(size_t)ff_tile(it.i + 1, it.c)]++;
@@ -1521,13 +1536,15 @@ static int ff_build(ipm_handle* h) {
     const size_t nit = h->ff_sched.items.size();
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * nit));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, h->ff_sched.items.data(), sizeof(FFItem) * nit, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_tile_items, sizeof(int) * ntile));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ff_tile_items, h->ff_sched.tile_items.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
     h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk;
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * 2 * h->ff_flag_words));     // live words + diagnostic snapshot
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)Q * 128 * 128));
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_part, sizeof(double) * 256));
     if (getenv("IPM_FF_PROF")) {
-        HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_prof, sizeof(long long) * 16 * (size_t)h->ff_workers));
-        HIP_TRY(h, hipMemsetAsync(h->ff_prof, 0, sizeof(long long) * 16 * (size_t)h->ff_workers, h->stream));
+        HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_prof, sizeof(long long) * (16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk)));
+        HIP_TRY(h, hipMemsetAsync(h->ff_prof, 0, sizeof(long long) * (16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk), h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ff_built = true;
@@ -1549,13 +1566,16 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
              *potrfdone = dready + nblk;
     unsigned* timeout = h->d_flags + 2 * (size_t)nblk;
     HIP_TRY(h, hipMemsetAsync(F, 0, sizeof(unsigned) * h->ff_flag_words, sw));
-    HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
-    HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
-    // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
-    // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
-    // formation chunks -- the first diagonal tile is not ready before those are done anyway
-    hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
-                       &h->sc->maxdiag, done);
+    const bool inker = h->ff_chain_in_kernel != 0;
+    if (!inker) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
+        HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
+        // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
+        // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
+        // formation chunks -- the first diagonal tile is not ready before those are done anyway
+        hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
+                           &h->sc->maxdiag, done);
+    }
     FFArgs a;
     memset(&a, 0, sizeof a);
     a.A = h->A; a.lda = h->np; a.d = h->d; a.B = h->B; a.ldb = h->mp; a.invD = h->invD; a.slab = h->ff_slab;
@@ -1564,12 +1584,17 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     a.timeout = timeout; a.dbg = dbg; a.done = done;
     { static const bool dbg_on = getenv("IPM_FF_DEBUG") != nullptr; a.dbg_words = dbg_on ? (unsigned)h->ff_flag_words : 0u; }
     a.prof = h->ff_prof;
+    a.cprof = h->ff_prof ? h->ff_prof + 16 * ((size_t)h->ff_workers + 1) : nullptr;
+    a.chain_in_kernel = inker ? 1 : 0; a.tile_items = h->d_ff_tile_items;
+    a.maxbits = (unsigned long long*)(F + 8); a.dcount = F + 10; a.maxdiag_out = &h->sc->maxdiag;
+    a.eps = h->opt.pivot_guard_eps; a.big = h->opt.pivot_guard_big; a.shift_rel = h->shift_rel; a.fixed = &h->sc->fixed;
     a.nblk = nblk; a.Q = h->ff_q; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
-    hipLaunchKernelGGL(form_factor_kernel, dim3((unsigned)h->ff_workers), dim3(FF_THREADS), 0, sw, a);
+    hipLaunchKernelGGL(form_factor_kernel, dim3((unsigned)h->ff_workers + (inker ? 1u : 0u)), dim3(FF_THREADS), 0, sw, a);
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], sw));
     HIP_TRY(h, hipGetLastError());
     h->n_counter_steps = 0; h->n_event_steps = 0; h->last_gs = 1;
+    if (inker) { h->n_counter_steps = nblk; h->ff_last = true; return IPM_OK; }      // the chain is workgroup 0 of that launch
     for (int k = 0; k < nblk; ++k) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
@@ -1622,6 +1647,7 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     FFModel M;
     M.f_stages = std::max(1, 512 / q); M.nstages = 512;       // K = 8192 (the headline size's formation), BK = 16 stages
     if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) { M.nstages = std::max(q, atoi(e)); M.f_stages = (M.nstages + q - 1) / q; }
+    if (!(getenv("IPM_FF_CHAIN") && !strcmp(getenv("IPM_FF_CHAIN"), "launches"))) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
     ff_build_schedule(nblk, q, workers, M, S);
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));
@@ -1852,7 +1878,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
         const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
         static const bool ff_overlap = !(getenv("IPM_FF_OVERLAP") && atoi(getenv("IPM_FF_OVERLAP")) == 0);
-        if (fused && !ff_overlap) {
+        if (fused && (!ff_overlap || h->ff_chain_in_kernel)) {
             // experiment: no residual-stream work beside the fused launch -- residuals, group inverses after it, in stream order
             if ((rc = enqueue_form_factor(h, ev, -1, -1))) return rc;
             h->fdone = nullptr;

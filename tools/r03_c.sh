@@ -1,9 +1,9 @@
 #!/bin/bash
-# fused path: tests, then a sweep of Q / workers / order weights at the headline size (bench lines), one trace
+# fused path: tests, then a sweep at the headline size (bench lines) -- chain in the kernel (default) against the chain as launches
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_fused_factor.py -x -q > $O/c_pytest.log 2>&1 || { tail -40 $O/c_pytest.log; exit 1; }
+IPM_FF_DEBUG=1 timeout -k 10 600 python -m pytest tests/test_gpu_fused_factor.py -x -q > $O/c_pytest.log 2>&1 || { tail -60 $O/c_pytest.log; exit 1; }
 tail -1 $O/c_pytest.log
 run() {  # name, env...
   local name=$1; shift
@@ -13,10 +13,12 @@ import json,sys
 d=json.loads(open("gpurun_out/c_%s.json"%sys.argv[1]).read().strip().splitlines()[-1])
 print("%-28s it/s %7.2f ms %.3f %s worker-kernel ms %.3f" % (sys.argv[1], d["value"], d["ms_per_step"], d["objective_check"], d["phases_ms_per_step"]["form"]))
 PY
+  grep -A10 "ff prof" $O/c_$name.err | head -12
 }
 run serial IPM_FUSED_FACTOR=0
-for q in 4 8 16; do run ff_q${q} IPM_FF_Q=$q; done
-run ff_q8_w240 IPM_FF_Q=8 IPM_FF_WORKERS=240 || true
-run ff_q8_colmajor IPM_FF_Q=8 IPM_FF_ROW_WEIGHT=0 IPM_FF_COL_WEIGHT=1
-run ff_q8_w2140 IPM_FF_Q=8 IPM_FF_ROW_WEIGHT=21 IPM_FF_COL_WEIGHT=40
-run ff_q8_nooverlap IPM_FF_Q=8 IPM_FF_OVERLAP=0
+run ff_launches IPM_FF_CHAIN=launches
+run ff_inkernel_q4 IPM_FF_Q=4 IPM_FF_PROF=1
+run ff_inkernel_q8 IPM_FF_Q=8
+run ff_inkernel_q4_b8 IPM_FF_Q=4 IPM_FF_BATCH=8
+run ff_inkernel_q4_colmajor IPM_FF_Q=4 IPM_FF_ROW_WEIGHT=0 IPM_FF_COL_WEIGHT=1
+run ff_inkernel_q4_w2140 IPM_FF_Q=4 IPM_FF_ROW_WEIGHT=21 IPM_FF_COL_WEIGHT=40

@@ -62,13 +62,19 @@ constexpr int FF_MAX_NBLK = 96;
 FF_HD inline int ff_tile(int i, int c) { return i * (i + 1) / 2 + c; }
 
 struct FFModel {                       // durations in microseconds (MI355X, one 512-thread workgroup per CU)
-    double stage = 4.6;                // one BK = 32 stage of a 128 x 128 tile (update / panel items; 4.2-4.4 standalone)
-    double pstage = 4.4;               // one BK = 16 stage of a 256 x 128 tile PAIR (formation): 9280 cycles at the 2.1 GHz the
-                                       // chip holds inside the fused launch (in-kernel cycle profile; 3.91 us standalone)
-    double f_overhead = 8.0;           // F chunk: prologue + slab stores + drain
-    double t_overhead = 14.0;          // T item: ticket, wait + acquire, tile load, combine, store + drain (cycle profile: 10.5 + 3 us)
-    double t_base = 4.0;               // reading Q slabs
-    double t_panel = 19.0;             // second product with inv(L_cc) (4 stages + staging through LDS; profile: 19 us)
+    double stage = 4.4;                // one BK = 32 stage of a 128 x 128 tile (update / panel items; 4.2-4.4 standalone)
+    double pstage = 3.95;              // one BK = 16 stage of a 256 x 128 tile PAIR (formation): 3.91 us standalone; inside the fused
+                                       // launch 9280 cycles at the 2.1 GHz the chip holds there = 4.4 us (in-kernel cycle profile)
+    // The durations below are DELIBERATELY on the optimistic side of what the cycle profile shows (T overhead 10.5 + 3 us,
+    // panel product 19 us, formation stage 4.4 us): the list is drawn in order with blocking waits, and an order that
+    // expects the chain's inputs early puts a worker in front of each of them before it is ready, so that the hand-off
+    // costs no pick-up time.  Measured at 4096 x 8192, 224 workers: 3.91 ms with these values, 4.19-4.26 ms with the
+    // profile's own; drawing ready items without waiting (IPM_FF_CLAIM=1) 4.88 ms -- the launch is bound by the chain's
+    // dependencies, not by the order of the list.
+    double f_overhead = 6.0;           // F chunk: prologue + slab stores + drain
+    double t_overhead = 7.0;           // T item: ticket, wait + acquire, tile load, combine, store + drain
+    double t_base = 2.0;               // reading Q slabs
+    double t_panel = 16.0;             // second product with inv(L_cc) (4 stages + staging through LDS)
     int batch = 4, window = 2;         // columns per deferred batch; chain look-ahead (FF_BATCH / FF_WINDOW)
     int chain_in_kernel = 0;           // 1: the chain is workgroup 0 of the launch (no launch boundaries; FF_D items head the list)
     double d_item = 140.0;             // one FF_D item

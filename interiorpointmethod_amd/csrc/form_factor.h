@@ -45,7 +45,19 @@ struct FFArgs {
     double* B; int64_t ldb;            // [mp][ldb]: tiles, then L in place
     const double* invD;                // [nblk][128*128] inv(L_kk), written by potrf_diag
     double* slab;                      // [ntile][Q][128*128] formation partials
-    const FFItem* items; int nitems;
+    const FFItem* items; int nitems;   // the whole list in simulated order (claim == 0: one ticket counter, blocking waits)
+    // claim == 1 (IPM_FF_CLAIM=1, not the default: measured slower): formation chunks and update items are drawn SEPARATELY -- a worker first looks for an update item
+    // that is READY among the first unclaimed ones of the T list (non-blocking checks of the item's hand-off words, the 64
+    // lanes of one wave look at 64 items at once), claims it, and only otherwise takes the next formation chunk: nobody waits
+    // while there is formation work, whatever the simulation got wrong about the timing.  With the formation exhausted the
+    // workers wait for the head items of the T list as before (bounded spins).
+    int claim;
+    int wt;                            // 1: hand-off data stored write-through (sc1), no release; 0: plain stores + one agent-scope release
+    const FFItem* fitems; int nf;      // FF_F / FF_D items, in order
+    const FFItem* titems; int nt;      // FF_T items, in priority order
+    unsigned* fticket;                 // next formation item
+    unsigned* thead;                   // every T item before this index is claimed
+    unsigned* claimed;                 // [nt]
     unsigned* ticket;                  // [1] next item
     unsigned* fcount;                  // [ntile] formation chunks complete
     unsigned* tprog;                   // [ntile] T items complete (sequence number)
@@ -355,9 +367,13 @@ __device__ __forceinline__ void ff_gemm_pair(const double* __restrict__ P0, cons
 // additional formation chunk cost 160-260 us with it (Q = 8 / 16 against Q = 4), and the chain's own kernels, which do
 // release, took 22-25 us instead of 7-10.
 __device__ __forceinline__ void ff_store_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ff_publish_begin() {
+__device__ __forceinline__ void ff_publish_begin(bool release = false) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (release && threadIdx.x == 0) {          // plain-store form (FFArgs::wt == 0): one lane releases for the workgroup
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -542,10 +558,14 @@ __device__ __attribute__((noinline)) void ff_chain_role(const FFArgs& g, double*
 enum { FFP_TICKET = 0, FFP_FGEMM, FFP_FSTORE, FFP_TWAIT, FFP_TGEMM, FFP_TBASE, FFP_PWAIT, FFP_PGEMM, FFP_TSTORE, FFP_NF, FFP_NT, FFP_TOTAL };
 #define FF_PROF(slot) do { if (g.prof && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); g.prof[(size_t)blockIdx.x * 16 + (slot)] += t_ - tprev; tprev = t_; } } while (0)
 
+// CLAIM / INKER / WT: the three opt-in variants (FFArgs::claim, ::chain_in_kernel, ::wt) are separate instantiations, so that
+// the shipped one carries none of their code: the worker loop sits at the register limit and every extra path costs spills.
+template <bool CLAIM, bool INKER, bool WT>
 __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     if (g.done && *g.done) return;
     __shared__ __attribute__((aligned(16))) double lds[FF_LDS_DOUBLES];
-    __shared__ unsigned ticket_s;
+    __shared__ unsigned ticket_s, f_left_s, head_s;
+    __shared__ unsigned long long mask_s[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -553,20 +573,95 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     // this lane's 32 elements of a 128 x 128 tile (accumulator layout): row = er + i*16 + 4q, col = ec + j*16
     const int er = wm * 64 + fk, ec = wn * 32 + fr;
 
-    if (g.chain_in_kernel && blockIdx.x == 0) { ff_chain_role(g, lds); return; }
+    if (INKER && blockIdx.x == 0) { ff_chain_role(g, lds); return; }
     long long tprev = g.prof ? __builtin_amdgcn_s_memtime() : 0;
     const long long tstart = tprev;
+    if (threadIdx.x == 0) f_left_s = 1u;                    // formation items may be left
+    __syncthreads();
     for (;;) {
-        if (tid == 0) ticket_s = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        constexpr unsigned SEL_EXIT = 0xffffffffu, SEL_T = 0x80000000u;
+        if (!CLAIM) {
+            if (tid == 0) {
+                const unsigned n0 = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket_s = n0 < (unsigned)g.nitems ? n0 : SEL_EXIT;
+            }
+        } else if constexpr (CLAIM) {
+            // all 8 waves look at the 512 update items behind the head: the first READY unclaimed one is claimed
+            for (unsigned spins = 0;; ++spins) {
+                if (tid == 0) head_s = __hip_atomic_load(g.thead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const unsigned h = head_s;                    // ONE head for the whole window (other workgroups move it meanwhile)
+                const unsigned n = h + (unsigned)tid;
+                bool open = false, cand = false;
+                if (n < (unsigned)g.nt) {
+                    // every load of a lane is issued before the first is used: two memory latencies per look, not seven
+                    const unsigned cl = __hip_atomic_load(g.claimed + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const FFItem ti_ = g.titems[n];
+                    const int tl = ff_tile(ti_.i, ti_.c);
+                    const unsigned v_f = __hip_atomic_load(g.fcount + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v_t = __hip_atomic_load(g.tprog + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v_i = __hip_atomic_load(g.lfinal + ti_.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v_c = __hip_atomic_load(g.lfinal + ti_.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v_p = __hip_atomic_load(g.potrfdone + ti_.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    open = cl == 0u;
+                    bool ok = open;
+                    if (ti_.t.flags & FF_ADD_BASE) ok = ok & (v_f >= (unsigned)g.Q);
+                    if (!(ti_.t.flags & FF_INIT)) ok = ok & (v_t >= (unsigned)ti_.t.seq - 1u);
+                    if (ti_.t.j1 > ti_.t.j0) ok = ok & (v_i >= 4u * ti_.t.j1) & (v_c >= 4u * ti_.t.j1);
+                    if (ti_.t.flags & FF_PANEL) ok = ok & (v_p >= 1u);
+                    cand = ok;
+                }
+                const unsigned long long mask = __ballot(cand), openmask = __ballot(open);
+                if (lane == 0) { mask_s[wave] = mask; mask_s[8 + wave] = openmask; }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned first_open = 0xffffffffu;
+                    for (int w8 = 7; w8 >= 0; --w8) if (mask_s[8 + w8]) first_open = h + 64u * (unsigned)w8 + (unsigned)__builtin_ctzll(mask_s[8 + w8]);
+                    unsigned sel = 0xfffffffeu;                          // "look again"
+                    bool any_ready = false;
+                    // the ready items in list order: the first one nobody else has taken meanwhile
+                    for (int w8 = 0; w8 < 8 && sel == 0xfffffffeu; ++w8) {
+                        unsigned long long mk = mask_s[w8];
+                        while (mk) {
+                            any_ready = true;
+                            const unsigned c_ = h + 64u * (unsigned)w8 + (unsigned)__builtin_ctzll(mk);
+                            if (__hip_atomic_exchange(g.claimed + c_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { sel = SEL_T | c_; break; }
+                            mk &= mk - 1;
+                        }
+                    }
+                    if (any_ready) {
+                        // (every ready item was snatched: look again)
+                    } else {
+                        // the head moves over the claimed prefix of the window
+                        const unsigned nh = first_open != 0xffffffffu ? first_open : min(h + 512u, (unsigned)g.nt);
+                        if (nh > h) __hip_atomic_fetch_max(g.thead, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (f_left_s) {
+                            const unsigned fn = __hip_atomic_fetch_add(g.fticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (fn < (unsigned)g.nf) sel = fn; else f_left_s = 0u;
+                        }
+                        if (sel == 0xfffffffeu && !f_left_s) {
+                            // no formation work left: back to the ORDERED form -- take the first open item whether it is ready or
+                            // not and wait for it inside (one lane polls its hand-off words; hundreds of idle workgroups scanning
+                            // the list would only take memory bandwidth from the workgroups that still compute)
+                            if (first_open == 0xffffffffu) { if (nh >= (unsigned)g.nt) sel = SEL_EXIT; }
+                            else if (__hip_atomic_exchange(g.claimed + first_open, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) sel = SEL_T | first_open;
+                        }
+                    }
+                    ticket_s = sel;
+                }
+                __syncthreads();
+                if (ticket_s != 0xfffffffeu) break;
+            }
+        }
         __syncthreads();
         const unsigned n = ticket_s;
         __syncthreads();                                   // ticket_s is rewritten on the next turn
-        if (n >= (unsigned)g.nitems) { if (g.prof && tid == 0) g.prof[(size_t)blockIdx.x * 16 + FFP_TOTAL] = __builtin_amdgcn_s_memtime() - tstart; return; }
-        const FFItem it = g.items[n];
+        if (n == SEL_EXIT) { if (g.prof && tid == 0) g.prof[(size_t)blockIdx.x * 16 + FFP_TOTAL] = __builtin_amdgcn_s_memtime() - tstart; return; }
+        const FFItem it = !CLAIM ? g.items[n] : ((n & SEL_T) ? g.titems[n & ~SEL_T] : g.fitems[n]);
         FF_PROF(FFP_TICKET);
         const int ti = it.i, tc = it.c;
         const int tile = ff_tile(ti, tc);
-        if (it.type == FF_D) {
+        if (INKER && it.type == FF_D) {
             // ---- diag(B) of the true rows of block ti straight from A and d -> running maximum (the pivot guard's scale): one
             //      wave per row, 16 rows per wave; max of non-negative doubles through their bit patterns (order independent)
             double mx = 0.0;
@@ -617,10 +712,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) ff_store_wt(sb + (i * 16 + 4 * q) * 128 + j * 16, pacc[i][j][q]);
+                            for (int q = 0; q < 4; ++q) { if (WT) ff_store_wt(sb + (i * 16 + 4 * q) * 128 + j * 16, pacc[i][j][q]); else sb[(i * 16 + 4 * q) * 128 + j * 16] = pacc[i][j][q]; }
                 }
             }
-            ff_publish_begin();
+            ff_publish_begin(!WT);
             if (tid == 0) {
                 if (up) __hip_atomic_fetch_add(g.fcount + ff_tile(ti, tc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lo) __hip_atomic_fetch_add(g.fcount + ff_tile(ti + 1, tc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -722,8 +817,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ff_store_wt(bt + (int64_t)(i * 16 + 4 * q) * g.ldb + j * 16, val[i][j][q]);
-        ff_publish_begin();
+                for (int q = 0; q < 4; ++q) { if (WT) ff_store_wt(bt + (int64_t)(i * 16 + 4 * q) * g.ldb + j * 16, val[i][j][q]); else bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16] = val[i][j][q]; }
+        ff_publish_begin(!WT);
         if (tid == 0) {
             __hip_atomic_store(g.tprog + tile, (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (flags & FF_PANEL) __hip_atomic_fetch_add(g.lfinal + ti, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

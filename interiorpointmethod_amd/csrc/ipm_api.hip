@@ -138,11 +138,19 @@ struct ipm_handle {
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
     int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: all CUs but one with
                                           // the chain in the kernel, 7/8 of the CUs with the chain as launches on a second stream)
-    int ff_chain_in_kernel = 1;           // IPM_FF_CHAIN=launches: the pivot chain as three kernel launches per step (round-3 first version)
+    int ff_chain_in_kernel = 0;           // IPM_FF_CHAIN=kernel: the pivot chain as workgroup 0 of the persistent launch instead of three kernel
+                                          // launches per step on the second stream.  Built, correct, SLOWER: one CU needs 34 + 22 us for the panel solve and
+                                          // the tile update of a step (the launches spread them over 4 + 10 workgroups: 12 + 7 us) and potrf itself runs at
+                                          // 46-58 us beside the workers' memory traffic: 115 us per step against 56 (profiles/r03_ff_chain_in_kernel_prof.txt)
     int* d_ff_tile_items = nullptr;
     bool ff_built = false, ff_last = false;
     FFSchedule ff_sched;
-    FFItem* d_ff_items = nullptr;
+    FFItem* d_ff_items = nullptr;         // [all | F and D items | T items]
+    int ff_nf = 0, ff_nt = 0;
+    int ff_claim = 0;                     // IPM_FF_CLAIM=1: update items are drawn when READY (non-blocking look at the first 512 open ones), formation
+                                          // chunks otherwise -- built, correct, slower (4.88 against 3.91 ms: the launch is dependency bound, and a worker
+                                          // already waiting in front of an item picks it up with no latency); default: ONE ticket counter over the simulated
+                                          // order, blocking waits
     unsigned* d_ff_flags = nullptr;       // ticket[16] | maxdiag ticket[16] | fcount[ntile] | tprog[ntile] | lfinal[nblk] | dready[nblk] | potrfdone[nblk]
     size_t ff_flag_words = 0;
     double* ff_slab = nullptr;            // [ntile][Q][128*128]
@@ -517,7 +525,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; } else h->ff_enabled = atoi(e); }
     if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
-    if (const char* e = getenv("IPM_FF_CHAIN")) h->ff_chain_in_kernel = strcmp(e, "launches") != 0;
+    if (const char* e = getenv("IPM_FF_CLAIM")) h->ff_claim = atoi(e);
+    if (const char* e = getenv("IPM_FF_CHAIN")) h->ff_chain_in_kernel = strcmp(e, "kernel") == 0;
     if (const char* e = getenv("IPM_FF_Q")) h->ff_q = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("IPM_FF_WORKERS")) h->ff_workers = std::max(1, atoi(e));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_ffjoin, hipEventDisableTiming));
@@ -1534,11 +1543,17 @@ static int ff_build(ipm_handle* h) {
             }
     }
     const size_t nit = h->ff_sched.items.size();
-    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * nit));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, h->ff_sched.items.data(), sizeof(FFItem) * nit, hipMemcpyHostToDevice, h->stream));
+    std::vector<FFItem> all(h->ff_sched.items), fl, tl;
+    for (const FFItem& it : h->ff_sched.items) (it.type == FF_T ? tl : fl).push_back(it);
+    h->ff_nf = (int)fl.size(); h->ff_nt = (int)tl.size();
+    all.insert(all.end(), fl.begin(), fl.end());
+    all.insert(all.end(), tl.begin(), tl.end());
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * all.size()));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, all.data(), sizeof(FFItem) * all.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));          // (`all` is a local)
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_tile_items, sizeof(int) * ntile));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_tile_items, h->ff_sched.tile_items.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
-    h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk;
+    h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk + (size_t)h->ff_nt;      // ... | claimed[nT]
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * 2 * h->ff_flag_words));     // live words + diagnostic snapshot
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)Q * 128 * 128));
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_part, sizeof(double) * 256));
@@ -1580,6 +1595,12 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     memset(&a, 0, sizeof a);
     a.A = h->A; a.lda = h->np; a.d = h->d; a.B = h->B; a.ldb = h->mp; a.invD = h->invD; a.slab = h->ff_slab;
     a.items = h->d_ff_items; a.nitems = (int)h->ff_sched.items.size();
+    a.claim = h->ff_claim ? 1 : 0;
+    // IPM_FF_WT=1: write-through hand-off stores instead of plain stores + one release per item -- measured slower (8-byte sc1
+    // stores: 4.55 against 4.21 ms in an A/B of one build)
+    { static const int wt = getenv("IPM_FF_WT") ? atoi(getenv("IPM_FF_WT")) : 0; a.wt = wt; }
+    a.fitems = h->d_ff_items + a.nitems; a.nf = h->ff_nf; a.titems = a.fitems + h->ff_nf; a.nt = h->ff_nt;
+    a.fticket = F + 1; a.thead = F + 2; a.claimed = potrfdone + nblk;
     a.ticket = ticket; a.fcount = fcount; a.tprog = tprog; a.lfinal = lfinal; a.dready = dready; a.potrfdone = potrfdone;
     a.timeout = timeout; a.dbg = dbg; a.done = done;
     { static const bool dbg_on = getenv("IPM_FF_DEBUG") != nullptr; a.dbg_words = dbg_on ? (unsigned)h->ff_flag_words : 0u; }
@@ -1590,7 +1611,13 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     a.eps = h->opt.pivot_guard_eps; a.big = h->opt.pivot_guard_big; a.shift_rel = h->shift_rel; a.fixed = &h->sc->fixed;
     a.nblk = nblk; a.Q = h->ff_q; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
-    hipLaunchKernelGGL(form_factor_kernel, dim3((unsigned)h->ff_workers + (inker ? 1u : 0u)), dim3(FF_THREADS), 0, sw, a);
+    {
+        const dim3 grid((unsigned)h->ff_workers + (inker ? 1u : 0u));
+        if (inker) hipLaunchKernelGGL((form_factor_kernel<false, true, false>), grid, dim3(FF_THREADS), 0, sw, a);
+        else if (a.claim) hipLaunchKernelGGL((form_factor_kernel<true, false, false>), grid, dim3(FF_THREADS), 0, sw, a);
+        else if (a.wt) hipLaunchKernelGGL((form_factor_kernel<false, false, true>), grid, dim3(FF_THREADS), 0, sw, a);
+        else hipLaunchKernelGGL((form_factor_kernel<false, false, false>), grid, dim3(FF_THREADS), 0, sw, a);
+    }
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], sw));
     HIP_TRY(h, hipGetLastError());
     h->n_counter_steps = 0; h->n_event_steps = 0; h->last_gs = 1;
@@ -1647,7 +1674,7 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     FFModel M;
     M.f_stages = std::max(1, 512 / q); M.nstages = 512;       // K = 8192 (the headline size's formation), BK = 16 stages
     if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) { M.nstages = std::max(q, atoi(e)); M.f_stages = (M.nstages + q - 1) / q; }
-    if (!(getenv("IPM_FF_CHAIN") && !strcmp(getenv("IPM_FF_CHAIN"), "launches"))) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
+    if (getenv("IPM_FF_CHAIN") && !strcmp(getenv("IPM_FF_CHAIN"), "kernel")) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
     ff_build_schedule(nblk, q, workers, M, S);
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));

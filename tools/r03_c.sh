@@ -1,5 +1,5 @@
 #!/bin/bash
-# fused path: tests, then a sweep at the headline size (bench lines) -- chain in the kernel (default) against the chain as launches
+# fused path: tests, then bench lines at the headline size for the shipped configuration and its variants
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
@@ -13,12 +13,13 @@ import json,sys
 d=json.loads(open("gpurun_out/c_%s.json"%sys.argv[1]).read().strip().splitlines()[-1])
 print("%-28s it/s %7.2f ms %.3f %s worker-kernel ms %.3f" % (sys.argv[1], d["value"], d["ms_per_step"], d["objective_check"], d["phases_ms_per_step"]["form"]))
 PY
-  grep -A10 "ff prof" $O/c_$name.err | head -12
 }
 run serial IPM_FUSED_FACTOR=0
-run ff_launches IPM_FF_CHAIN=launches
-run ff_inkernel_q4 IPM_FF_Q=4 IPM_FF_PROF=1
-run ff_inkernel_q8 IPM_FF_Q=8
-run ff_inkernel_q4_b8 IPM_FF_Q=4 IPM_FF_BATCH=8
-run ff_inkernel_q4_colmajor IPM_FF_Q=4 IPM_FF_ROW_WEIGHT=0 IPM_FF_COL_WEIGHT=1
-run ff_inkernel_q4_w2140 IPM_FF_Q=4 IPM_FF_ROW_WEIGHT=21 IPM_FF_COL_WEIGHT=40
+run ff_default
+run ff_q6 IPM_FF_Q=6
+run ff_q3 IPM_FF_Q=3
+run ff_w2130 IPM_FF_ROW_WEIGHT=21 IPM_FF_COL_WEIGHT=30
+run ff_colmajor IPM_FF_ROW_WEIGHT=0 IPM_FF_COL_WEIGHT=1
+run ff_batch8 IPM_FF_BATCH=8
+run ff_window3 IPM_FF_WINDOW=3
+run ff_nostagger IPM_FF_STAGGER=0

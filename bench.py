@@ -40,18 +40,19 @@ RESET_EVERY = 20
 PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense fp64 matrix peak
 
 
-def kernel_source_sha():
-    """sha256 (first 16 hex) of the sources the dominant kernel is built from: a PMC pass collected for another
-    version of the kernel is refused (profiles/*_pmc_form_kernel.json carries the sha it was collected with)."""
+def kernel_source_sha(fused=False):
+    """sha256 (first 16 hex) of the sources the dominant kernel is built from -- adat_syrk_kernel on the serial path,
+    form_factor_kernel on the fused one: a PMC pass collected for another version of the kernel is refused
+    (profiles/*_pmc_form_kernel*.json carries the kernel name and the sha it was collected with)."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("adat_syrk_f64.h", "gemm_nt_f64.h"):
+    for f in ("adat_syrk_f64.h", "gemm_nt_f64.h") + (("form_factor.h", "ff_schedule.h") if fused else ()):
         with open(os.path.join(ROOT, "interiorpointmethod_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]
 
 
-def load_traffic(m, n):
+def load_traffic(m, n, fused=False):
     """(traffic bytes per launch | None, note).  HBM-side bytes of the dominant kernel from the newest committed PMC
     pass (tools/pmc_form_kernel.py), accepted only for the same problem size AND the same kernel source."""
     import glob
@@ -62,6 +63,8 @@ def load_traffic(m, n):
                 d = json.load(fh)
         except Exception:
             continue
+        if ("form_factor" in d.get("kernel", "")) != bool(fused):
+            continue                            # a pass of the other path's kernel
         if tuple(d.get("shape", ())) == (m, n):
             best = (f, d)                       # newest pass collected at this problem size
         else:
@@ -70,9 +73,9 @@ def load_traffic(m, n):
         return None, ("no PMC pass committed" if other is None else
                       "no PMC pass for %d x %d (newest is %s for shape %s)" % (m, n, os.path.basename(other[0]), other[1].get("shape")))
     f, d = best
-    if d.get("kernel_source_sha") != kernel_source_sha():
+    if d.get("kernel_source_sha") != kernel_source_sha(fused):
         return None, "stale: %s was collected for kernel source %s, current is %s" % (
-            os.path.basename(f), d.get("kernel_source_sha"), kernel_source_sha())
+            os.path.basename(f), d.get("kernel_source_sha"), kernel_source_sha(fused))
     return d["derived"]["traffic_bytes_per_launch"], "from %s (rocprofv3 --pmc, separate passes)" % os.path.basename(f)
 
 
@@ -450,6 +453,7 @@ def main():
         return total_ms, (form_ms, factor_ms, tri_ms, other_ms), st
 
     run(args.warmup)
+    fused = bool(sv.schedule().get("fused_factor"))       # the iteration ran the fused formation + factorization launch
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -474,9 +478,16 @@ def main():
         K = args.steps
         its_per_s = ngpu * K / elapsed
         form_ms = phases[0] / K
-        flops_form = float(m) * m * n                       # lower-triangle SYRK, SURVEY 8(d)
+        nblk = (m + 127) // 128
+        if fused:
+            # the dominant kernel is the persistent worker launch: the formation (m^2 n) AND the factorization's matrix work
+            # outside the pivot chain (m^3 / 3 minus, per 128-row block, the diagonal block's own factorization and the chain's
+            # panel solve and tile update: 128^3 (1/3 + 2 + 1) flop)
+            flops_form = float(m) * m * n + float(m) ** 3 / 3.0 - nblk * 128.0 ** 3 * (1.0 / 3.0 + 3.0)
+        else:
+            flops_form = float(m) * m * n                       # lower-triangle SYRK, SURVEY 8(d)
         achieved = flops_form / (form_ms * 1e-3) / 1e12 if form_ms > 0 else 0.0
-        traffic, traffic_src = load_traffic(m, n)      # HBM-side bytes per launch: PMC pass collected separately
+        traffic, traffic_src = load_traffic(m, n, fused)      # HBM-side bytes per launch: PMC pass collected separately
         out = {
             "metric": "IPM iterations/sec (m=%d,n=%d dense LP)" % (m, n),
             "value": its_per_s, "unit": "iterations/s", "n_gpus": ngpu, "steps": K, "warmup": args.warmup,
@@ -491,13 +502,18 @@ def main():
                          "traffic_source": traffic_src,
                          "traffic_note": "L2<->fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), null when "
                                          "the committed PMC pass was collected for another kernel source or size; algorithmic "
-                                         "bytes 8mn + 4m^2",
-                         "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
-                         "kernel": "adat_syrk_kernel (B = A diag(d) A^T, lower 128x128 tiles, v_mfma_f64_16x16x4_f64)",
+                                         "bytes 8mn + 4m^2 (+ 4m^2 for L when the launch also factors)",
+                         "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m * (2.0 if fused else 1.0),
+                         "kernel": ("form_factor_kernel (persistent launch beside the pivot chain: B = A diag(d) A^T in 256x128 tile pairs + every "
+                                    "trailing update and panel solve of the Cholesky outside the chain, v_mfma_f64_16x16x4_f64; 224 of 256 CUs)"
+                                    if fused else "adat_syrk_kernel (B = A diag(d) A^T, lower 128x128 tiles, v_mfma_f64_16x16x4_f64)"),
+                         "fused_formation_and_factorization": fused,
                          "flops_per_launch": flops_form, "avg_launch_ms": form_ms},
-            "phases_ms_per_step": {"form": form_ms, "factor": phases_all[1] / KB, "trisolve": phases_all[2] / KB,
+            "phases_ms_per_step": {"form": form_ms, "form_is": "the fused worker launch (formation + factorization beside the chain)" if fused else "the formation kernel",
+                                   "factor": phases_all[1] / KB, "trisolve": phases_all[2] / KB,
                                    "other": phases_all[3] / KB, "device_total": dev_ms / K,
-                                   "note": "form and device_total from the timed region; the rest from an untimed pass"},
+                                   "note": "form and device_total from the timed region; the rest from an untimed pass"
+                                           + (" on the SERIAL path (formation then factorization, what profiling level 2 runs): its form + factor is what the fused launch replaces" if fused else "")},
             "whole_iteration": {"flops_per_iteration": flops_per_iteration(m, n),
                                 "tflops": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12,
                                 "frac_of_fp64_mfma_peak": flops_per_iteration(m, n) * its_per_s / ngpu / 1e12 / PEAK_FP64_MFMA_TFLOPS},

@@ -76,6 +76,11 @@ struct FFModel {                       // durations in microseconds (MI355X, one
     double t_base = 2.0;               // reading Q slabs
     double t_panel = 16.0;             // second product with inv(L_cc) (4 stages + staging through LDS)
     int batch = 4, window = 2;         // columns per deferred batch; chain look-ahead (FF_BATCH / FF_WINDOW)
+    int q_first = 8, q_second = 4;     // formation chunks per tile for the block rows 0-3 / 4-7 (capped by the slab capacity): the chain
+                                       // cannot start before the first diagonal tile is formed -- at 0.98 ms of a 3.96 ms launch with
+                                       // four staggered chunks (profiles/r03_ff_timeline_iter.txt).  Measured, worker launch in ms for
+                                       // (q_first, q_second) = (4,4) / (8,4) / (16,8) / (16,16): 3.99 / 3.91 / 4.25 / 4.22 -- an even
+                                       // earlier start only brings the read-modify-write passes of the updates forward
     int chain_in_kernel = 0;           // 1: the chain is workgroup 0 of the launch (no launch boundaries; FF_D items head the list)
     double d_item = 140.0;             // one FF_D item
     double potrf = 38.0, crit_panel = 8.0, crit_update = 6.0, boundary = 3.0;
@@ -88,6 +93,7 @@ struct FFModel {                       // durations in microseconds (MI355X, one
 struct FFSchedule {
     std::vector<FFItem> items;
     std::vector<int> tile_items;       // [ntile] T items per tile (what the chain waits for on its tiles)
+    std::vector<int> tile_q;           // [ntile] formation chunks (slabs) of the tile: more for the tiles the chain needs first
     double makespan_us = 0.0;          // simulated end of the factorization
     double form_end_us = 0.0;          // simulated end of the last formation chunk
 };
@@ -96,7 +102,9 @@ struct FFSchedule {
 inline int ff_limit(int i, int c) { return (i == c) ? (c > 0 ? c - 1 : 0) : c; }
 inline bool ff_needs_panel(int i, int c) { return i > c + 1; }
 
-inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSchedule& out) {
+// Q: formation chunks per tile (ordinary tiles); Qmax: slab capacity per tile (>= Q; the first block rows use up to it).
+inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSchedule& out, int Qmax = 0) {
+    if (Qmax < Q) Qmax = Q;
     const double INF = std::numeric_limits<double>::infinity();
     const int ntile = nblk * (nblk + 1) / 2;
     const bool trace = getenv("IPM_FF_TRACE") != nullptr;
@@ -106,10 +114,13 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     if (const char* e = getenv("IPM_FF_STAGGER")) Mx.stagger = atoi(e);
     if (const char* e = getenv("IPM_FF_BATCH")) Mx.batch = std::max(1, atoi(e));
     if (const char* e = getenv("IPM_FF_WINDOW")) Mx.window = std::max(1, atoi(e));
+    if (const char* e = getenv("IPM_FF_Q_FIRST")) Mx.q_first = std::max(1, atoi(e));
+    if (const char* e = getenv("IPM_FF_Q_SECOND")) Mx.q_second = std::max(1, atoi(e));
     const FFModel& M = Mx;
     struct Tile {
         int i, c, limit; bool panel;
         int f_sched = 0; double f_time = 0.0;          // F chunks scheduled, latest finish
+        int qn = 0;                                    // F chunks of the tile
         bool base_in = false, paneled = false;
         int applied = 0, nitems = 0;
         double ready = 0.0;                            // finish time of the last T item scheduled on the tile
@@ -144,32 +155,45 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
                 order.push_back(Pair{key, i, c});
             }
         std::stable_sort(order.begin(), order.end(), [&](const Pair& a, const Pair& b) { return a.key != b.key ? a.key < b.key : a.c < b.c; });
-        // Chunk boundaries in (BK = 16) stages.  Uniform, except for the FIRST band (the items every worker starts with): there
-        // the chunk lengths are spread over 0.4 .. 1.6 of the mean, so that the workers do not finish their formation chunks in
-        // lockstep -- with equal chunks all of them are deaf for one whole chunk (hundreds of microseconds) at the same time,
-        // and everything the chain waits for waits with them; staggered, one worker comes free every microsecond or so.
+        // Chunks per pair: Q, but more for the block rows the chain needs first (FFModel::q_first / q_second), so that the
+        // first diagonal tiles are complete after ~150 us instead of a whole long chunk.
+        // Chunk boundaries in (BK = 16) stages.  Uniform, except for the first band of ordinary pairs (the items most workers
+        // start with): there the chunk lengths are spread over 0.4 .. 1.6 of the mean, so that the workers do not finish their
+        // formation chunks in lockstep -- with equal chunks all of them are deaf for one whole chunk (hundreds of microseconds)
+        // at the same time, and everything the chain waits for waits with them; staggered, one worker comes free every
+        // microsecond or so.
         const int ns = M.nstages;
-        const size_t band = (size_t)std::max(1, W / std::max(1, Q));
-        for (size_t b0 = 0; b0 < order.size(); b0 += band) {
-            const size_t b1 = std::min(order.size(), b0 + band);
-            std::vector<std::vector<int>> cut(b1 - b0, std::vector<int>((size_t)Q + 1, 0));
+        auto pair_q = [&](const Pair& p) { const int q = p.i < 4 ? M.q_first : (p.i < 8 ? M.q_second : Q); return std::max(1, std::min(std::min(q, Qmax), ns)); };
+        size_t b0 = 0;
+        bool first_band = true;
+        while (b0 < order.size()) {
+            const int qb = pair_q(order[b0]);
+            const size_t band = (size_t)std::max(1, W / qb);
+            size_t b1 = b0;
+            while (b1 < order.size() && b1 < b0 + band && pair_q(order[b1]) == qb) ++b1;
+            std::vector<std::vector<int>> cut(b1 - b0, std::vector<int>((size_t)qb + 1, 0));
+            const bool stag = qb == Q && first_band && Q > 1 && M.stagger;
+            if (qb == Q) first_band = false;
             for (size_t t = b0; t < b1; ++t) {
-                std::vector<double> len((size_t)Q, 1.0);
-                if (b0 == 0 && Q > 1 && M.stagger) {
-                    const double phi = (double)(t - b0) / (double)(b1 - b0) / Q;
-                    for (int q = 0; q < Q; ++q) { double u = (double)q / Q + phi; u -= (double)(int)u; len[(size_t)q] = 0.4 + 1.2 * u; }
+                std::vector<double> len((size_t)qb, 1.0);
+                if (stag) {
+                    const double phi = (double)(t - b0) / (double)(b1 - b0) / qb;
+                    for (int q = 0; q < qb; ++q) { double u = (double)q / qb + phi; u -= (double)(int)u; len[(size_t)q] = 0.4 + 1.2 * u; }
                 }
                 double tot = 0.0; for (double v : len) tot += v;
                 double acc = 0.0;
-                for (int q = 0; q < Q; ++q) { acc += len[(size_t)q]; cut[t - b0][(size_t)q + 1] = (int)(ns * acc / tot + 0.5); }
-                cut[t - b0][(size_t)Q] = ns;
+                for (int q = 0; q < qb; ++q) { acc += len[(size_t)q]; cut[t - b0][(size_t)q + 1] = (int)(ns * acc / tot + 0.5); }
+                cut[t - b0][(size_t)qb] = ns;
+                if (order[t].c <= order[t].i) T[(size_t)ff_tile(order[t].i, order[t].c)].qn = qb;
+                if (order[t].i + 1 < nblk) T[(size_t)ff_tile(order[t].i + 1, order[t].c)].qn = qb;
             }
-            for (int q = 0; q < Q; ++q)
+            for (int q = 0; q < qb; ++q)
                 for (size_t t = b0; t < b1; ++t) {
                     FFItem it{}; it.type = FF_F; it.i = (unsigned char)order[t].i; it.c = (unsigned char)order[t].c; it.q = (unsigned char)q;
                     it.f.s0 = (unsigned short)cut[t - b0][(size_t)q]; it.f.s1 = (unsigned short)cut[t - b0][(size_t)q + 1];
                     forder.push_back(it);
                 }
+            b0 = b1;
         }
     }
     size_t fnext = 0;
@@ -241,7 +265,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
         for (int id = 0; id < ntile; ++id) {
             const Tile& x = T[(size_t)id];
             if (x.complete() || x.ready > t) continue;             // done, or an item of the tile is in flight
-            const bool fc = x.f_sched == Q && x.f_time <= t;
+            const bool fc = x.f_sched == x.qn && x.f_time <= t;
             const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
             const int pend = a - x.applied;
             const bool can_base = fc && !x.base_in;
@@ -286,7 +310,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
         }
         // ---- a T item on tile `best`
         Tile& x = T[(size_t)best];
-        const bool fc = x.f_sched == Q && x.f_time <= t;
+        const bool fc = x.f_sched == x.qn && x.f_time <= t;
         const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
         FFItem it{};
         it.type = FF_T; it.i = (unsigned char)x.i; it.c = (unsigned char)x.c;
@@ -313,7 +337,8 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     }
     advance_chain();
     out.tile_items.assign((size_t)ntile, 0);
-    for (int id = 0; id < ntile; ++id) out.tile_items[(size_t)id] = T[(size_t)id].nitems;
+    out.tile_q.assign((size_t)ntile, 0);
+    for (int id = 0; id < ntile; ++id) { out.tile_items[(size_t)id] = T[(size_t)id].nitems; out.tile_q[(size_t)id] = T[(size_t)id].qn; }
     if (out.makespan_us == 0.0) out.makespan_us = chain_free;
 }
 

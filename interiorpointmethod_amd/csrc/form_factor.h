@@ -70,11 +70,12 @@ struct FFArgs {
     long long* prof;                   // diagnostic (may be null): [workgroups][16] cycles per phase (s_memtime), see FF_PROF
     long long* cprof;                  // diagnostic (may be null): chain role, [nblk][4] s_memtime at: inputs of P ready, P done, D done, potrf done
     const int* done;
-    int nblk, Q, nstages, fstages;     // nstages = K / 16 of the formation (BK = 16 stages of the pair engine), fstages = stages per chunk
+    int nblk, Q, nstages, fstages;     // Q = slab capacity per tile; nstages = K / 16 of the formation (BK = 16 stages of the pair engine)
     int m;                             // true rows: padding rows get a unit diagonal
     // chain role (workgroup 0 of the launch when chain_in_kernel != 0): the pivot chain without kernel launches
     int chain_in_kernel;
     const int* tile_items;             // [ntile] T items per tile (what the chain waits for on its tiles)
+    const int* tile_q;                 // [ntile] formation chunks (slabs in use) of the tile, <= Q
     unsigned long long* maxbits;       // max diag(B) over the true rows as the bit pattern of a non-negative double (FF_D items)
     unsigned* dcount;                  // FF_D items complete
     double* maxdiag_out;               // Scalars::maxdiag (for the record)
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
                     const unsigned v_p = __hip_atomic_load(g.potrfdone + ti_.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     open = cl == 0u;
                     bool ok = open;
-                    if (ti_.t.flags & FF_ADD_BASE) ok = ok & (v_f >= (unsigned)g.Q);
+                    if (ti_.t.flags & FF_ADD_BASE) ok = ok & (v_f >= (unsigned)g.tile_q[tl]);
                     if (!(ti_.t.flags & FF_INIT)) ok = ok & (v_t >= (unsigned)ti_.t.seq - 1u);
                     if (ti_.t.j1 > ti_.t.j0) ok = ok & (v_i >= 4u * ti_.t.j1) & (v_c >= 4u * ti_.t.j1);
                     if (ti_.t.flags & FF_PANEL) ok = ok & (v_p >= 1u);
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         const int j0 = it.t.j0, j1 = it.t.j1;
         const int flags = it.t.flags, seq = it.t.seq;
         if (tid == 0) {
-            if (flags & FF_ADD_BASE) ff_wait_ge(g.fcount + tile, (unsigned)g.Q, g.timeout, g.dbg, n, 1, g.dbg_words);
+            if (flags & FF_ADD_BASE) ff_wait_ge(g.fcount + tile, (unsigned)g.tile_q[tile], g.timeout, g.dbg, n, 1, g.dbg_words);
             if (!(flags & FF_INIT)) ff_wait_ge(g.tprog + tile, (unsigned)seq - 1u, g.timeout, g.dbg, n, 2, g.dbg_words);
             if (j1 > j0) {
                 ff_wait_ge(g.lfinal + ti, 4u * (unsigned)j1, g.timeout, g.dbg, n, 3, g.dbg_words);
@@ -765,7 +766,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
                     for (int q = 0; q < 4; ++q) val[i][j][q] = bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16];
         }
         if (flags & FF_ADD_BASE) {
-            for (int c = 0; c < g.Q; ++c) {
+            const int qn = g.tile_q[tile];
+            for (int c = 0; c < qn; ++c) {
                 const double* sb = g.slab + ((size_t)tile * g.Q + c) * (128 * 128) + er * 128 + ec;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)

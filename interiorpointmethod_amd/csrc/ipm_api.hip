@@ -134,7 +134,13 @@ struct ipm_handle {
     // fused formation + factorization (form_factor.h): dense handles of FF_MIN_NBLK .. FF_MAX_NBLK blocks that have the device to
     // themselves run ONE persistent worker launch beside the pivot chain instead of formation followed by factorization
     int ff_enabled = 1;                   // IPM_FUSED_FACTOR=0 disables, =force also below FF_MIN_NBLK blocks (tests)
-    int ff_min_nblk = 16, ff_max_nblk = 40;   // beyond ~48 blocks the two-level serial schedule is the measured default (IPM_FF_MAX_NBLK)
+    // Where the fused launch is the default.  Measured on MI355X, it/s fused / serial (tools/ff_sizes.sh, n = 2m unless noted):
+    // 2048: 595 / 646 -- 2560: 396 / 386 -- 3072: 379 / 301 -- 3584: 232 / 211 -- 4096: 216-218 / 206 -- 5120: 124 / 111 --
+    // 4096 x 4608: 299 / 262 -- 4096 x 16384: 128 / 140 (the formation dominates there, and 224 workers form slower than the
+    // serial kernel on all 256 CUs).  So: from 20 blocks on, up to 40 (beyond ~48 the two-level serial schedule is the measured
+    // default), and only while n <= 3 m.  IPM_FF_MAX_NBLK / IPM_FUSED_FACTOR=force|0 override.
+    int ff_min_nblk = 20, ff_max_nblk = 40;
+    bool ff_forced = false;
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
     int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: all CUs but one with
                                           // the chain in the kernel, 7/8 of the CUs with the chain as launches on a second stream)
@@ -142,7 +148,8 @@ struct ipm_handle {
                                           // launches per step on the second stream.  Built, correct, SLOWER: one CU needs 34 + 22 us for the panel solve and
                                           // the tile update of a step (the launches spread them over 4 + 10 workgroups: 12 + 7 us) and potrf itself runs at
                                           // 46-58 us beside the workers' memory traffic: 115 us per step against 56 (profiles/r03_ff_chain_in_kernel_prof.txt)
-    int* d_ff_tile_items = nullptr;
+    int* d_ff_tile_items = nullptr;       // [tile_items | tile_q]
+    int ff_qmax = 16;                     // slab capacity per tile (the first block rows are formed in more, shorter chunks)
     bool ff_built = false, ff_last = false;
     FFSchedule ff_sched;
     FFItem* d_ff_items = nullptr;         // [all | F and D items | T items]
@@ -523,7 +530,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
-    if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; } else h->ff_enabled = atoi(e); }
+    if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; h->ff_forced = true; } else h->ff_enabled = atoi(e); }
     if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
     if (const char* e = getenv("IPM_FF_CLAIM")) h->ff_claim = atoi(e);
     if (const char* e = getenv("IPM_FF_CHAIN")) h->ff_chain_in_kernel = strcmp(e, "kernel") == 0;
@@ -1493,6 +1500,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
 static bool ff_ok(const ipm_handle* h) {
     if (!h->ff_enabled || h->sparse || h->lookahead == 0 || h->stream2 == nullptr || h->flag_sync == 0) return false;
     if (h->nblk < h->ff_min_nblk || h->nblk > std::min(h->ff_max_nblk, FF_MAX_NBLK) || h->np % FF_PBK) return false;
+    if (!h->ff_forced && h->np > 3 * h->mp) return false;
     return h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
 }
 
@@ -1518,7 +1526,8 @@ static int ff_build(ipm_handle* h) {
     FFModel M;
     M.f_stages = (nstages + Q - 1) / Q; M.nstages = nstages;
     if (h->ff_chain_in_kernel) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
-    ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched);
+    h->ff_qmax = std::max(Q, std::min(16, nstages));
+    ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched, h->ff_qmax);
     const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
     {   // every tile complete?  (an incomplete list would be an internal error of the scheduler, never a reason to hang a GPU)
         std::vector<int> fcnt(ntile, 0), base(ntile, 0), applied(ntile, 0), paneled(ntile, 0);
@@ -1538,7 +1547,7 @@ static int ff_build(ipm_handle* h) {
         for (int i = 0; i < h->nblk; ++i)
             for (int c = 0; c <= i; ++c) {
                 const size_t t = (size_t)ff_tile(i, c);
-                if (fcnt[t] != Q || base[t] != 1 || applied[t] != ff_limit(i, c) || paneled[t] != (ff_needs_panel(i, c) ? 1 : 0))
+                if (fcnt[t] != h->ff_sched.tile_q[t] || base[t] != 1 || applied[t] != ff_limit(i, c) || paneled[t] != (ff_needs_panel(i, c) ? 1 : 0))
                     return fail(h, IPM_ERR_INVALID_ARG, "fused factor: internal error (tile %d,%d incomplete in the work list)", i, c);
             }
     }
@@ -1551,11 +1560,12 @@ static int ff_build(ipm_handle* h) {
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * all.size()));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, all.data(), sizeof(FFItem) * all.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));          // (`all` is a local)
-    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_tile_items, sizeof(int) * ntile));
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_tile_items, sizeof(int) * 2 * ntile));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_tile_items, h->ff_sched.tile_items.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ff_tile_items + ntile, h->ff_sched.tile_q.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
     h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk + (size_t)h->ff_nt;      // ... | claimed[nT]
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * 2 * h->ff_flag_words));     // live words + diagnostic snapshot
-    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)Q * 128 * 128));
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)h->ff_qmax * 128 * 128));
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_part, sizeof(double) * 256));
     if (getenv("IPM_FF_PROF")) {
         HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_prof, sizeof(long long) * (16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk)));
@@ -1606,10 +1616,10 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     { static const bool dbg_on = getenv("IPM_FF_DEBUG") != nullptr; a.dbg_words = dbg_on ? (unsigned)h->ff_flag_words : 0u; }
     a.prof = h->ff_prof;
     a.cprof = h->ff_prof ? h->ff_prof + 16 * ((size_t)h->ff_workers + 1) : nullptr;
-    a.chain_in_kernel = inker ? 1 : 0; a.tile_items = h->d_ff_tile_items;
+    a.chain_in_kernel = inker ? 1 : 0; a.tile_items = h->d_ff_tile_items; a.tile_q = h->d_ff_tile_items + ntile;
     a.maxbits = (unsigned long long*)(F + 8); a.dcount = F + 10; a.maxdiag_out = &h->sc->maxdiag;
     a.eps = h->opt.pivot_guard_eps; a.big = h->opt.pivot_guard_big; a.shift_rel = h->shift_rel; a.fixed = &h->sc->fixed;
-    a.nblk = nblk; a.Q = h->ff_q; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
+    a.nblk = nblk; a.Q = h->ff_qmax; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
     {
         const dim3 grid((unsigned)h->ff_workers + (inker ? 1u : 0u));
@@ -1675,7 +1685,7 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     M.f_stages = std::max(1, 512 / q); M.nstages = 512;       // K = 8192 (the headline size's formation), BK = 16 stages
     if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) { M.nstages = std::max(q, atoi(e)); M.f_stages = (M.nstages + q - 1) / q; }
     if (getenv("IPM_FF_CHAIN") && !strcmp(getenv("IPM_FF_CHAIN"), "kernel")) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
-    ff_build_schedule(nblk, q, workers, M, S);
+    ff_build_schedule(nblk, q, workers, M, S, std::max(q, 16));
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));
     if (tile_items) for (size_t t = 0; t < S.tile_items.size(); ++t) tile_items[t] = S.tile_items[t];

@@ -76,6 +76,14 @@ def replay(nblk, q, items, tile_items):
                 chain["k"], chain["phase"] = k + 1, 0
 
     fcover = {}
+    # chunks per tile: q for ordinary tiles, more (shorter ones) for the block rows the chain needs first
+    qtile = np.zeros(ntile, int)
+    for (typ, i, c, qq, *_r) in items:
+        if typ == F:
+            for ii in (i, i + 1):
+                if c <= ii < nblk:
+                    qtile[tid(ii, c)] = max(qtile[tid(ii, c)], qq + 1)
+    assert qtile.min() >= 1 and np.all(qtile[tid(nblk - 1, 0):] == min(q, 512)) or nblk <= 8
     for n, (typ, i, c, qq, j0, j1, flags, seq, s0, s1) in enumerate(items):
         if typ == D:                         # max diag(B) of row block i: the items the chain-in-kernel launch starts with
             assert n < nblk and i == n
@@ -86,21 +94,20 @@ def replay(nblk, q, items, tile_items):
         t = tid(i, c) if c <= i else -1
         if typ == F:
             # a formation item covers the tile PAIR (i, c), (i + 1, c), i even (a half above the diagonal / below the matrix is dropped)
-            assert i % 2 == 0 and c <= min(i + 1, nblk - 1) and 0 <= qq < q and 0 <= s0 <= s1 <= NSTAGES
+            assert i % 2 == 0 and c <= min(i + 1, nblk - 1) and 0 <= qq < 16 and 0 <= s0 <= s1 <= NSTAGES
             for ii in (i, i + 1):
                 if c <= ii < nblk:
                     tt = tid(ii, c)
                     assert (tt, qq) not in fcover
                     fcover[(tt, qq)] = (s0, s1)
                     fcount[tt] += 1
-                    assert fcount[tt] <= q
             continue
         assert typ == T
         assert seq == nit[t] + 1, (n, i, c, "sequence")
         assert bool(flags & INIT) == (nit[t] == 0), (n, i, c, "INIT on the first item only")
         assert j0 == applied[t] and j0 <= j1 <= limit(i, c), (n, i, c, j0, j1)
         if flags & ADD_BASE:
-            assert fcount[t] == q and base[t] == 0, (n, i, c, "base before its chunks, or twice")
+            assert fcount[t] == qtile[t] and base[t] == 0, (n, i, c, "base before its chunks, or twice")
             base[t] = 1
         for j in range(j0, j1):
             assert final[i][j] and final[c][j], (n, i, c, j, "operand tile not final at this point of the list")
@@ -117,9 +124,9 @@ def replay(nblk, q, items, tile_items):
     for i in range(nblk):
         for c in range(i + 1):
             t = tid(i, c)
-            cuts = sorted(fcover[(t, k)] for k in range(q))           # the chunks tile the K loop exactly once
+            cuts = sorted(fcover[(t, k)] for k in range(qtile[t]))    # the chunks tile the K loop exactly once
             assert cuts[0][0] == 0 and cuts[-1][1] == NSTAGES and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])), (i, c, cuts)
-            assert fcount[t] == q and base[t] == 1 and applied[t] == limit(i, c), (i, c)
+            assert fcount[t] == qtile[t] and base[t] == 1 and applied[t] == limit(i, c), (i, c)
             assert paneled[t] == (1 if needs_panel(i, c) else 0) and nit[t] == tile_items[t] >= 1, (i, c)
     return chain["k"]
 

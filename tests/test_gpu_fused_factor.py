@@ -46,11 +46,11 @@ def test_fused_path_matches_the_serial_path(monkeypatch, m, n):
 
 
 def test_fused_path_full_solve_and_factor_against_lapack(monkeypatch):
-    """A whole solve on the fused path at 17 blocks (default limit: on without `force`): converges like the serial path
+    """A whole solve on the fused path at 21 blocks (default rule: on from 20 blocks, without `force`): converges like the serial path
     (same iteration count, objective 1e-9), the LP-level properties hold on the host, and the factor the handle holds
     after convergence is the complete Cholesky factor of the final normal matrix (L L^T = A D^2 A^T to 1e-12: the latch
     of the overlapped path keeps the last factorization whole)."""
-    m, n = 2100, 4300
+    m, n = 2600, 5300
     A, b, c = synthetic_lp(m, n, seed=11)
     res = {}
     for mode in ("0", "1"):
@@ -78,7 +78,7 @@ def test_fused_path_factor_of_a_given_scaling(monkeypatch):
     rng = np.random.default_rng(3)
     A, b, c = synthetic_lp(m, n, seed=2)
     x = rng.uniform(0.5, 2.0, n); s = rng.uniform(0.5, 2.0, n); y = rng.standard_normal(m)
-    monkeypatch.setenv("IPM_FUSED_FACTOR", "1")
+    monkeypatch.setenv("IPM_FUSED_FACTOR", "force")
     with ipm.IpmSolver(A, b, c) as sv:
         sv.set_state(x, y, s)
         sv.iterate(1)
@@ -87,3 +87,14 @@ def test_fused_path_factor_of_a_given_scaling(monkeypatch):
     B = (A * (x / s)) @ A.T
     Lref = np.linalg.cholesky(B)
     assert rel(L, Lref) < 1e-10
+
+
+def test_default_rule_selects_the_fused_path_where_it_was_measured_faster():
+    """The selection rule (ipm_api.hip: from 20 blocks on, up to 40, n <= 3 m): the headline size runs fused, a wide LP
+    (formation-dominated) and a small one do not."""
+    for (m, n), want in (((4096, 8192), 1), ((2048, 4096), 0), ((2560, 10240), 0)):
+        A, b, c = synthetic_lp(m, n, seed=1)
+        with ipm.IpmSolver(A, b, c) as sv:
+            sv.init_state(0.0)
+            sv.iterate(1)
+            assert sv.schedule()["fused_factor"] == want, (m, n)

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", required=True)
     ap.add_argument("--shape", type=int, nargs=2, default=[4096, 8192])
-    ap.add_argument("--kernel", default="adat_syrk_kernel")
+    ap.add_argument("--kernel", default="adat_syrk_kernel", help="adat_syrk_kernel (serial path) or form_factor_kernel (fused path)")
     args = ap.parse_args()
     import bench
     acc = collections.defaultdict(list)
@@ -57,7 +57,12 @@ def main():
     out["derived"] = der
     out["shape"] = [m, n]
     out["kernel"] = args.kernel
-    out["kernel_source_sha"] = bench.kernel_source_sha()
+    out["kernel_source_sha"] = bench.kernel_source_sha(fused="form_factor" in args.kernel)
+    if "form_factor" in args.kernel:
+        out["note"] = ("the launch runs BESIDE the pivot chain's kernels and the residual stream (other queues): the per-dispatch SQ / GRBM "
+                       "counters of overlapping dispatches are not separable, only the TCC byte counters are used; MFMA occupancy of this "
+                       "launch: its in-kernel cycle profile (profiles/r03_ff_cycle_profile.txt)")
+        out["derived"] = {k: v for k, v in out["derived"].items() if not k.startswith("mfma_busy")}
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -16,10 +16,10 @@ PY
 }
 run serial IPM_FUSED_FACTOR=0
 run ff_default
-run ff_q6 IPM_FF_Q=6
-run ff_q3 IPM_FF_Q=3
-run ff_w2130 IPM_FF_ROW_WEIGHT=21 IPM_FF_COL_WEIGHT=30
+run ff_first4 IPM_FF_Q_FIRST=4 IPM_FF_Q_SECOND=4
+run ff_first16_16 IPM_FF_Q_FIRST=16 IPM_FF_Q_SECOND=16
+run ff_first8_4 IPM_FF_Q_FIRST=8 IPM_FF_Q_SECOND=4
 run ff_colmajor IPM_FF_ROW_WEIGHT=0 IPM_FF_COL_WEIGHT=1
-run ff_batch8 IPM_FF_BATCH=8
-run ff_window3 IPM_FF_WINDOW=3
+run ff_w2140 IPM_FF_ROW_WEIGHT=21 IPM_FF_COL_WEIGHT=40
 run ff_nostagger IPM_FF_STAGGER=0
+run ff_q6 IPM_FF_Q=6

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libipm_hip.so")
 
 # symbols declared in include/ipm_hip.h (checked by tests/test_abi.py against the header)
 EXPORTS = [
-    "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc",
+    "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc", "ipm_workspace_bytes_opts",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
     "ipm_iterate", "ipm_solve", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
@@ -107,6 +107,7 @@ def load():
     lib.ipm_default_options.restype = None
     lib.ipm_workspace_bytes.argtypes = [i64, i64, C.POINTER(C.c_size_t)]
     lib.ipm_workspace_bytes_csc.argtypes = [i64, i64, i64, C.POINTER(C.c_size_t)]
+    lib.ipm_workspace_bytes_opts.argtypes = [i64, i64, C.POINTER(Options), C.POINTER(C.c_size_t)]
     lib.ipm_create.argtypes = [C.c_int, i64, i64, C.POINTER(Options), vp, C.c_size_t, vp, C.POINTER(vp)]
     lib.ipm_destroy.argtypes = [vp]
     lib.ipm_last_error.argtypes = [vp]

@@ -19,6 +19,7 @@
 #include "../../include/ipm_hip.h"
 #include "gemm_nt_f64.h"
 #include "adat_syrk_f64.h"
+#include "chol_update_f64.h"
 #include "chol_crit_f64.h"
 #include "potrf_f64.h"
 #include "sparse_ops.h"
@@ -74,10 +75,14 @@ struct ipm_handle {
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
     unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
+    bool no_dense = false;                // B / invD / slab are not in the workspace (layout_no_dense); B_own, invD_own once ensure_dense_B ran
+    double* B_own = nullptr; double* invD_own = nullptr;
+    int* d_upd_order = nullptr;           // 2-D patch orders of the lower tiles of every trailing-matrix size (tile (0,0) left out): table of nt tiles per side
+    std::vector<int> upd_order_off;       // at d_upd_order + upd_order_off[nt]; empty: row-major enumeration (small handles, IPM_UPDATE_ORDER=0)
     int group_steps = 0;                  // > 0: forced group size of the two-level schedule
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
-    int bulk_variant = 0;                 // 1: BK=32 tiles for the bulk trailing update (measured slower: 2.38 vs 2.26 ms)
+    int bulk_variant = 0;                 // 0: chol_update_kernel (adat_syrk schedule, round 3); 7: the generic kernel of rounds 1-2; 1: BK=32 tiles (measured slower: 2.38 vs 2.26 ms)
     int crit_variant = 1;                 // critical-path GEMMs: 1 = 32-row tiles of the generic kernel, 0 = its plain tiles,
                                           // 2 = single-stage register kernels (chol_crit_f64.h; measured SLOWER: their
                                           // fragment-shaped 8-byte loads take 7.4 us, profiles/r02_crit_probe.log)
@@ -284,7 +289,11 @@ struct Layout {
 static const int N_NVEC = 11;   // x s c rc d v q dxa dsa dx ds
 static const int N_MVEC = 7;    // y b rb t1 t2 dya dy
 
-static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
+// no_dense: the handle factors with the sparse multifrontal Cholesky (IPM_FLAG_SPARSE_FACTOR on a sparse handle beyond the fused
+// small-LP size) -- B, inv(L_kk) and the split-K slab are not part of the workspace; ensure_dense_B allocates them if a
+// dense entry point (ipm_form_normal_matrix, ipm_get_factor, ipm_solve_linear) is ever called on such a handle.
+static bool layout_no_dense(int64_t m, int64_t sparse_nnz, unsigned flags) { return sparse_nnz > 0 && (flags & IPM_FLAG_SPARSE_FACTOR) && m > 128; }
+static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0, bool no_dense = false) {
     Layout L;
     L.mp = round_up(m, NB);
     {   // the grouped triangular solves (trsv_grouped.h) need whole 1024-row groups: pad a little further when that
@@ -306,8 +315,8 @@ static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     if (sparse_nnz > 0) { L.rc_chunks = 1; L.rows_per_chunk = (int)L.mp; }
     L.off_A = take(sparse_nnz > 0 ? 0 : sizeof(double) * L.mp * L.np);
-    L.off_B = take(sizeof(double) * L.mp * L.mp);
-    L.off_inv = take(sizeof(double) * L.nblk * NB * NB);
+    L.off_B = take(no_dense ? 0 : sizeof(double) * L.mp * L.mp);
+    L.off_inv = take(no_dense ? 0 : sizeof(double) * L.nblk * NB * NB);
     L.off_nvec = take(sizeof(double) * L.np * N_NVEC);
     L.off_mvec = take(sizeof(double) * L.mp * N_MVEC);
     L.off_atp = take(sizeof(double) * L.rc_chunks * L.np);
@@ -316,7 +325,7 @@ static Layout make_layout(int64_t m, int64_t n, int64_t sparse_nnz = 0) {
     L.off_fixed = take(256);
     L.off_hist = take(sizeof(IterRec) * HIST_CAP);
     L.off_snap = take(sizeof(double) * (2 * L.np + L.mp) + sizeof(Scalars));
-    L.off_slab = take(sizeof(double) * (size_t)kSlabTiles * 128 * 128);   // split-K partial tiles (64 MB)
+    L.off_slab = take(no_dense ? 0 : sizeof(double) * (size_t)kSlabTiles * 128 * 128);   // split-K partial tiles (64 MB)
     L.off_order = take(sizeof(int) * ((size_t)L.nblk * (L.nblk + 1) / 2));
     L.off_rowptr = take(sparse_nnz > 0 ? sizeof(int) * (m + 1) : 0);
     L.off_colptr = take(sparse_nnz > 0 ? sizeof(int) * (n + 1) : 0);
@@ -363,6 +372,13 @@ extern "C" int ipm_workspace_bytes_csc(int64_t m, int64_t n, int64_t nnz, size_t
     return IPM_OK;
 }
 
+extern "C" int ipm_workspace_bytes_opts(int64_t m, int64_t n, const ipm_options* opts, size_t* bytes) {
+    if (!bytes || m <= 0 || n <= 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "bad arguments to ipm_workspace_bytes_opts");
+    const int64_t nnz = opts && opts->sparse_nnz > 0 ? opts->sparse_nnz : 0;
+    *bytes = make_layout(m, n, nnz, layout_no_dense(m, nnz, opts ? opts->flags : 0u)).total;
+    return IPM_OK;
+}
+
 // ------------------------------------------------------------------------------- handle
 __global__ void set_params_kernel(Scalars* sc, double e1, double e2, double e3, double eta, int max_iter,
                                   int force, int reset) {
@@ -392,7 +408,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.sparse_nnz < 0) h->opt.sparse_nnz = 0;
     h->sparse = h->opt.sparse_nnz > 0;
     h->nnz_cap = h->opt.sparse_nnz;
-    Layout L = make_layout(m, n, h->opt.sparse_nnz);
+    h->no_dense = layout_no_dense(m, h->opt.sparse_nnz, h->opt.flags);
+    Layout L = make_layout(m, n, h->opt.sparse_nnz, h->no_dense);
     h->m = m; h->n = n; h->mp = L.mp; h->np = L.np; h->nblk = L.nblk;
     h->rc_chunks = L.rc_chunks; h->rows_per_chunk = L.rows_per_chunk; h->vblk = L.vblk;
     h->ws_bytes = L.total;
@@ -421,8 +438,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     }
     char* base = (char*)h->ws;
     h->A = (double*)(base + L.off_A);
-    h->B = (double*)(base + L.off_B);
-    h->invD = (double*)(base + L.off_inv);
+    h->B = h->no_dense ? nullptr : (double*)(base + L.off_B);
+    h->invD = h->no_dense ? nullptr : (double*)(base + L.off_inv);
     double* nv = (double*)(base + L.off_nvec);
     h->x = nv; h->s = nv + L.np; h->c = nv + 2 * L.np; h->rc = nv + 3 * L.np; h->d = nv + 4 * L.np;
     h->v = nv + 5 * L.np; h->q = nv + 6 * L.np; h->dxa = nv + 7 * L.np; h->dsa = nv + 8 * L.np;
@@ -436,7 +453,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->fixed = (int*)(base + L.off_fixed);
     h->hist = (IterRec*)(base + L.off_hist);
     h->snap = (double*)(base + L.off_snap);
-    h->slab = (double*)(base + L.off_slab);
+    h->slab = h->no_dense ? nullptr : (double*)(base + L.off_slab);
     h->d_tile_order = (int*)(base + L.off_order);
     {   // lower tiles enumerated super-block by super-block (8 x 8 tiles): the ~64 workgroups an XCD runs
         // at once then share 8 + 8 operand panels in that XCD's L2 instead of 1 + 64
@@ -470,6 +487,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.flags & IPM_FLAG_SINGLE_STREAM) h->lookahead = 0;
     if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
+    if (h->no_dense) h->grouped_trsv = 0;      // the sparse factor has its own sweeps; a dense entry point on such a handle solves block by block
     h->gsz = 0;
     if (h->grouped_trsv) {
         if (h->nblk >= 2 * GS_MAX) { if (h->nblk % GS_MAX == 0) h->gsz = GS_MAX; }
@@ -497,6 +515,27 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
+    {   // the bulk trailing updates enumerate their lower tiles super-block by super-block (8 x 8) like the formation: the ~64
+        // workgroups an XCD runs at once share 8 + 8 operand panels of L in its L2 instead of 1 + 64 (row-major order)
+        int on = h->nblk >= 24;
+        if (const char* e = getenv("IPM_UPDATE_ORDER")) on = atoi(e) && h->nblk >= 3;
+        if (on && !(h->opt.flags & IPM_FLAG_SPARSE_FACTOR)) {
+            std::vector<int> all;
+            h->upd_order_off.assign((size_t)h->nblk + 1, -1);
+            const int PB = 8;
+            for (int nt = 2; nt < h->nblk; ++nt) {
+                h->upd_order_off[(size_t)nt] = (int)all.size();
+                for (int I = 0; I * PB < nt; ++I)
+                    for (int J = 0; J <= I; ++J)
+                        for (int ti = I * PB; ti < nt && ti < (I + 1) * PB; ++ti)
+                            for (int tj = J * PB; tj <= ti && tj < (J + 1) * PB; ++tj)
+                                if (ti | tj) all.push_back((ti << 16) | tj);
+            }
+            CREATE_TRY(dev_malloc(device, h->stream, (void**)&h->d_upd_order, sizeof(int) * std::max<size_t>(1, all.size())));
+            CREATE_TRY(hipMemcpyAsync(h->d_upd_order, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, h->stream));
+            CREATE_TRY(hipStreamSynchronize(h->stream));
+        }
+    }
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
@@ -596,7 +635,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
-    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
+    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->d_upd_order, (void*)h->B_own, (void*)h->invD_own, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
                     (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof, (void*)h->d_ff_tile_items})
         dev_free(h->device, h->stream, p);
     free_sparse_factor(h);
@@ -1221,6 +1260,19 @@ static inline unsigned sp_launch_grid(ipm_handle* h) {
 }
 
 // B = A diag(d) A^T (lower tiles), unit diagonal on padding rows
+// Dense B and inv(L_kk) for a handle whose workspace carries none (layout_no_dense): allocated on first use by a dense entry
+// point, stream-ordered, freed in ipm_destroy.  A no-op everywhere else.
+static int ensure_dense_B(ipm_handle* h) {
+    if (h->B && h->invD) return IPM_OK;
+    if (!h->no_dense) return fail(h, IPM_ERR_STATE, "handle has no dense normal-matrix buffer");
+    if (dev_malloc(h->device, h->stream, (void**)&h->B_own, sizeof(double) * (size_t)h->mp * h->mp) != hipSuccess ||
+        dev_malloc(h->device, h->stream, (void**)&h->invD_own, sizeof(double) * (size_t)h->nblk * NB * NB) != hipSuccess)
+        return fail(h, IPM_ERR_HIP, "dense normal-matrix buffer (%lld x %lld doubles) could not be allocated", (long long)h->mp, (long long)h->mp);
+    HIP_TRY(h, hipMemsetAsync(h->invD_own, 0, sizeof(double) * (size_t)h->nblk * NB * NB, h->stream));
+    h->B = h->B_own; h->invD = h->invD_own;
+    return IPM_OK;
+}
+
 static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false) {
     if (sp_on(h) && !dense_image) {
         // the entries of B go straight into the panels of the sparse factor (one thread per slot, fixed term order)
@@ -1231,6 +1283,7 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }
+    if (int rc_ = ensure_dense_B(h)) return rc_;
     if (h->sparse && h->list_form) {
         const int64_t nB = h->mp * h->mp;                       // even (mp is a multiple of 128)
         hipLaunchKernelGGL(zero_unless_done_kernel, dim3((unsigned)std::min<int64_t>((nB / 2 + 255) / 256, 4096)), dim3(256), 0, h->stream,
@@ -1306,6 +1359,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }
+    if (int rc_ = ensure_dense_B(h)) return rc_;
     const int* done = h->fdone ? h->fdone : &h->sc->done;
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
@@ -1401,7 +1455,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         u.alpha = -1.0; u.beta = 1.0; u.lower = 1; u.unit_diag_from = -1; u.done = done;
         if (!la) {
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(t, sm)));
-            HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sm)));
+            if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sm)));
+            else HIP_TRY(h, launch_chol_update(u, sm));
             continue;
         }
         // one event per step on the main stream (after the critical panel rows): every extra record / wait
@@ -1466,7 +1521,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
                 ub.M = rem - NB; ub.N = std::min(wn * NB, rem); ub.lower = 0;
                 if (fs) { bulk_wgs[k] = (unsigned)((ub.M / NB) * (ub.N / NB)); ub.signal = h->d_bulk_done + k; ++h->n_counter_steps; }
                 else ++h->n_event_steps;
-                HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb)));
+                if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb)));
+                else HIP_TRY(h, launch_chol_update(ub, sb));
                 HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
                 continue;
             }
@@ -1481,7 +1537,11 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             if (h->bulk_variant == 1) HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
             else if (h->bulk_variant == 3) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // 8 waves per tile
             else if (h->bulk_variant == 4) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
-            else HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
+            else if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // the generic kernel (rounds 1-2)
+            else if (!h->upd_order_off.empty() && h->upd_order_off[(size_t)nt] >= 0) {
+                ub.tile_order = h->d_upd_order + h->upd_order_off[(size_t)nt];          // the table leaves tile (0,0) out itself
+                HIP_TRY(h, launch_chol_update(ub, sb, 0, nt * (nt + 1) / 2 - 1));
+            } else HIP_TRY(h, launch_chol_update(ub, sb, /*skip_first=*/1));
         }
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }
@@ -2399,6 +2459,7 @@ extern "C" int ipm_normal_solve(ipm_handle* h, const double* d, const double* rh
 extern "C" int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl) {
     if (!h || !L || ldl < h->m) return fail(h, IPM_ERR_INVALID_ARG, "ipm_get_factor: bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc_ = ensure_dense_B(h)) return rc_;
     if (h->spf) {                       // dense image of the sparse factor (the dense B buffer is free in this mode)
         HIP_TRY(h, hipMemsetAsync(h->B, 0, sizeof(double) * h->mp * h->mp, h->stream));
         hipLaunchKernelGGL(sp_expand_kernel, dim3((unsigned)h->spF.nsn), dim3(256), 0, h->stream, h->spF, h->B, (long long)h->mp);
@@ -2415,6 +2476,7 @@ extern "C" int ipm_get_factor(ipm_handle* h, double* L, int64_t ldl) {
 extern "C" int ipm_solve_linear(ipm_handle* h, const double* B, int64_t ldb, const double* rhs, double* z, int32_t* pivots_fixed) {
     if (!h || !B || !rhs || !z || ldb < h->m) return fail(h, IPM_ERR_INVALID_ARG, "ipm_solve_linear: bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc_ = ensure_dense_B(h)) return rc_;
     const int64_t m = h->m, mp = h->mp;
     std::vector<double> img((size_t)mp * mp, 0.0);
     for (int64_t i = 0; i < mp; ++i) {

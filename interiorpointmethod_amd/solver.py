@@ -236,7 +236,8 @@ class IpmSolver:
         self.sparse = _sp is not None and _sp.issparse(A)
         if self.sparse:                      # A stays sparse on the device (CSR + CSC, sparse formation of B)
             opts.sparse_nnz = int(A.nnz)
-            _lib.check(None, lib.ipm_workspace_bytes_csc(self.m, self.n, int(A.nnz), C.byref(nbytes)))
+            # (sized from the options: a sparse-factor handle carries no dense m x m normal matrix)
+            _lib.check(None, lib.ipm_workspace_bytes_opts(self.m, self.n, C.byref(opts), C.byref(nbytes)))
         else:
             _lib.check(None, lib.ipm_workspace_bytes(self.m, self.n, C.byref(nbytes)))
         self.workspace_bytes = nbytes.value

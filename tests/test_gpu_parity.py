@@ -581,6 +581,31 @@ def test_two_level_blocking_option(monkeypatch):
         assert abs(res[gs]["objective"] - res["1"]["objective"]) <= 1e-9 * (1 + abs(res["1"]["objective"]))
 
 
+def test_bulk_update_kernel_bit_identical_to_generic(monkeypatch):
+    """chol_update_kernel (adat_syrk stage schedule, buffer loads; csrc/chol_update_f64.h) against the generic
+    gemm_nt_f64_kernel<128,128,16,2,2> it replaced for the bulk trailing update (IPM_BULK_VARIANT=7): same tiling and
+    summation order, so the factor must be bitwise equal -- one-level (K = 128 lower updates), groups of 3 (rectangular
+    K = 128 windows + deferred K = 384 updates), with and without the look-ahead."""
+    rng = np.random.default_rng(33)
+    m = 1700
+    M = rng.standard_normal((m, m + 40))
+    B = M @ M.T + 0.5 * np.eye(m)
+    for env in ({}, {"IPM_GROUP_STEPS": "3"}, {"IPM_LOOKAHEAD": "0"}):
+        L = {}
+        for variant in ("0", "7"):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv("IPM_BULK_VARIANT", variant)
+            with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+                _, nfix = sv.solve_linear(B, np.ones(m))
+                L[variant] = sv.get_factor().copy()
+            assert nfix == 0
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(L["0"], L["7"]), env
+        assert rel(L["0"], np.linalg.cholesky(B)) < 1e-11
+
+
 def test_normal_solve_entry(golden_dir):
     """ipm_normal_solve: (A diag(d) A^T) z = rhs with the handle's own A, dense and sparse, factor reuse."""
     rng = np.random.default_rng(8)

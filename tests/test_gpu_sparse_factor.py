@@ -169,11 +169,18 @@ def test_solve_linear_on_a_sparse_factor_handle(golden_dir):
     Bd = M @ M.T + m * np.eye(m)
     rhs = rng.standard_normal(m)
     with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
+        ws_sparse = sv.workspace_bytes
         z0 = sv.normal_solve(rhs)
         zl, nfix = sv.solve_linear(Bd, rhs)
         z1 = sv.normal_solve(rhs)
     assert nfix == 0 and rel(zl.ravel(), np.linalg.solve(Bd, rhs)) < 1e-10
     assert np.array_equal(z0, z1)
+    # the workspace of a sparse-factor handle carries no dense m x m normal matrix (ipm_workspace_bytes_opts); the dense
+    # buffer solve_linear just used was allocated by the library on that first use
+    with ipm.IpmSolver(A, b, c, factor="dense") as sv:
+        ws_dense = sv.workspace_bytes
+    mp = -(-m // 128) * 128
+    assert ws_dense - ws_sparse >= 8 * mp * mp
 
 
 STRUCTURE_SWEEP = ["SCAGR7", "LOTFI", "E226", "BORE3D", "SCFXM1", "SCSD8", "GROW7", "DEGEN2", "SCRS8", "GFRD-PNC", "GROW15", "SCFXM3",

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(FF_THREADS, 2) void bench_kernel(const double* A, i
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) o[(i * 16 + 4 * q) * 128 + j * 16] = acc[i][j][q];
 }
 
-__global__ __launch_bounds__(FF_THREADS, 2) void bench_pair_kernel(const double* A, int64_t lda, const double* d, double* out, int ns16, int reps, int nblk) {
+// spread: 0 = every workgroup multiplies the SAME K range (the first 16 ns16 columns: 67 MB of A at ns16 = 128, Infinity-Cache resident);
+//         1 = workgroup b starts at column chunk (5 b + r) mod 4 (all of A in use at any time, as in the fused launch's pair-major list)
+__global__ __launch_bounds__(FF_THREADS, 2) void bench_pair_kernel(const double* A, int64_t lda, const double* d, double* out, int ns16, int reps, int nblk, int spread) {
     __shared__ __attribute__((aligned(16))) double lds[FF_LDS_DOUBLES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(FF_THREADS, 2) void bench_pair_kernel(const double*
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
     for (int r = 0; r < reps; ++r) {
         const int ti = 2 * ((blockIdx.x + 7 * r) % (nblk / 2)), tc = (blockIdx.x * 3 + r) % nblk;
-        ff_gemm_pair(A + (int64_t)ti * 128 * lda, A + (int64_t)(ti + 1) * 128 * lda, A + (int64_t)tc * 128 * lda, lda, d, ns16, lds, acc);
+        const int64_t ko = spread ? (int64_t)((5 * blockIdx.x + r) % 4) * 16 * ns16 : 0;
+        ff_gemm_pair(A + (int64_t)ti * 128 * lda + ko, A + (int64_t)(ti + 1) * 128 * lda + ko, A + (int64_t)tc * 128 * lda + ko, lda, d + ko, ns16, lds, acc);
     }
     double* o = out + (size_t)blockIdx.x * 256 * 128 + (wm * 64 + fk) * 128 + wn * 64 + fr;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) o[(i * 16 + 4 * q) * 128 + j * 16] = acc[i][j][q];
@@ -71,12 +74,13 @@ int main(int argc, char** argv) {
     {   // the pair engine: 256 x 128 per workgroup, BK = 16 stages (2 ns of them for the same K)
         double* o2; CK(hipMalloc(&o2, (size_t)W * 256 * 128 * 8));
         const double fl2 = (double)W * reps * (2 * ns) * 256.0 * 128.0 * 16.0 * 2.0;
-        for (int round = 0; round < 4; ++round) {
+        for (int round = 0; round < 8; ++round) {
+            const int spread = round >= 4;
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(bench_pair_kernel, dim3(W), dim3(FF_THREADS), 0, 0, A, (int64_t)n, d, o2, 2 * ns, reps, nblk);
+            hipLaunchKernelGGL(bench_pair_kernel, dim3(W), dim3(FF_THREADS), 0, 0, A, (int64_t)n, d, o2, 2 * ns, reps, nblk, spread);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (round) printf("pair engine: %.3f ms  %.1f TFLOP/s (%.3f of 78.6 on all 256 CUs; per BK=16 stage %.2f us)\n", ms, fl2 / ms / 1e9, fl2 / ms / 1e9 / 78.6,
+            if (round & 3) printf("pair engine (K ranges %s): %.3f ms  %.1f TFLOP/s (%.3f of 78.6 on all 256 CUs; per BK=16 stage %.2f us)\n", spread ? "spread over A" : "shared", ms, fl2 / ms / 1e9, fl2 / ms / 1e9 / 78.6,
                               ms * 1e3 / (reps * 2 * ns));
         }
     }

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
 #include <vector>
 
 #include "../../include/ipm_hip.h"
@@ -77,8 +78,6 @@ struct ipm_handle {
     unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
     bool no_dense = false;                // B / invD / slab are not in the workspace (layout_no_dense); B_own, invD_own once ensure_dense_B ran
     double* B_own = nullptr; double* invD_own = nullptr;
-    int* d_upd_order = nullptr;           // 2-D patch orders of the lower tiles of every trailing-matrix size (tile (0,0) left out): table of nt tiles per side
-    std::vector<int> upd_order_off;       // at d_upd_order + upd_order_off[nt]; empty: row-major enumeration (small handles, IPM_UPDATE_ORDER=0)
     int group_steps = 0;                  // > 0: forced group size of the two-level schedule
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
@@ -515,27 +514,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
-    {   // the bulk trailing updates enumerate their lower tiles super-block by super-block (8 x 8) like the formation: the ~64
-        // workgroups an XCD runs at once share 8 + 8 operand panels of L in its L2 instead of 1 + 64 (row-major order)
-        int on = h->nblk >= 24;
-        if (const char* e = getenv("IPM_UPDATE_ORDER")) on = atoi(e) && h->nblk >= 3;
-        if (on && !(h->opt.flags & IPM_FLAG_SPARSE_FACTOR)) {
-            std::vector<int> all;
-            h->upd_order_off.assign((size_t)h->nblk + 1, -1);
-            const int PB = 8;
-            for (int nt = 2; nt < h->nblk; ++nt) {
-                h->upd_order_off[(size_t)nt] = (int)all.size();
-                for (int I = 0; I * PB < nt; ++I)
-                    for (int J = 0; J <= I; ++J)
-                        for (int ti = I * PB; ti < nt && ti < (I + 1) * PB; ++ti)
-                            for (int tj = J * PB; tj <= ti && tj < (J + 1) * PB; ++tj)
-                                if (ti | tj) all.push_back((ti << 16) | tj);
-            }
-            CREATE_TRY(dev_malloc(device, h->stream, (void**)&h->d_upd_order, sizeof(int) * std::max<size_t>(1, all.size())));
-            CREATE_TRY(hipMemcpyAsync(h->d_upd_order, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, h->stream));
-            CREATE_TRY(hipStreamSynchronize(h->stream));
-        }
-    }
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
@@ -635,7 +613,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
-    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->d_upd_order, (void*)h->B_own, (void*)h->invD_own, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
+    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->B_own, (void*)h->invD_own, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
                     (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof, (void*)h->d_ff_tile_items})
         dev_free(h->device, h->stream, p);
     free_sparse_factor(h);
@@ -696,20 +674,39 @@ static int sp_alloc_zero(ipm_handle* h, size_t count, T** out) {
     return IPM_OK;
 }
 
+// ipm_order_rows analyses the LP in the order it returns; the caller then permutes the rows and calls ipm_set_A_csc, which needs
+// the same analysis: a few entries are kept (matched by the exact canonical CSC pattern of the permuted matrix, taken once).
+struct SymCacheEntry { int m = 0, n = 0; double relax = 1.0; std::vector<int> cp, ri; sym::Supernodes S; };
+static std::mutex g_sym_mutex;
+static std::deque<SymCacheEntry> g_sym_cache;
+static bool sym_cache_take(int m, int n, const std::vector<int>& cp, const std::vector<int>& ri, double relax, sym::Supernodes& S) {
+    std::lock_guard<std::mutex> lock(g_sym_mutex);
+    for (auto it = g_sym_cache.begin(); it != g_sym_cache.end(); ++it)
+        if (it->m == m && it->n == n && it->relax == relax && it->cp.size() == cp.size() && it->ri.size() == ri.size() &&
+            std::equal(cp.begin(), cp.end(), it->cp.begin()) && std::equal(ri.begin(), ri.end(), it->ri.begin())) {
+            S = std::move(it->S);
+            g_sym_cache.erase(it);
+            return true;
+        }
+    return false;
+}
+
 // Symbolic analysis of A A^T in the given row order, task partition, product lists of the formation; everything the three
 // kernels of sparse_chol.h index with goes to the device once.  cp/ri/cv: canonical CSC of A; rp/ci/rv: its CSR.
 static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const std::vector<int>& ri, const std::vector<double>& cv,
                                const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& rv) {
     free_sparse_factor(h);
     const int m = (int)h->m, n = (int)h->n;
-    sym::Pattern P;
-    if (!sym::normal_pattern(m, n, cp.data(), ri.data(), (int64_t)1.5e8, P))
-        return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: the pattern of A A^T exceeds 1.5e8 entries (use the dense path)");
     sym::Supernodes S;
     double relax = 1.0;
     if (const char* e = getenv("IPM_SP_RELAX")) relax = atof(e);
-    const int arc = sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax);
-    if (arc) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: the factor structures exceed 2.5e8 entries (use the dense path)");
+    if (!sym_cache_take(m, n, cp, ri, relax, S)) {          // not ordered through ipm_order_rows just before: analyse here
+        sym::Pattern P;
+        if (!sym::normal_pattern(m, n, cp.data(), ri.data(), (int64_t)1.5e8, P))
+            return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: the pattern of A A^T exceeds 1.5e8 entries (use the dense path)");
+        const int arc = sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax);
+        if (arc) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: the factor structures exceed 2.5e8 entries (use the dense path)");
+    }
     if (S.rmax > SPC_PANEL || S.panel_max > SPC_PANEL) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: a front of %d rows exceeds the panel budget", S.rmax);
     const int nsn = S.nsn;
     // ---- tasks: whole subtrees below a work threshold, chains of the remaining (top) panels
@@ -914,26 +911,34 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
     }
     std::vector<int> pv;
     sym::OrderInfo oi;
-    if (sym::order_rows((int)m, (int)n, colptr, rowind, pv, oi)) return fail(nullptr, IPM_ERR_WORKSPACE, "ipm_order_rows: A A^T is too dense for the sparse factor");
+    sym::Pattern P;                    // pattern of A A^T in the final order: formed once per LP, reused by the analysis below
+    if (sym::order_rows((int)m, (int)n, colptr, rowind, pv, oi, (int64_t)6e7, &P)) return fail(nullptr, IPM_ERR_WORKSPACE, "ipm_order_rows: A A^T is too dense for the sparse factor");
     for (int64_t i = 0; i < m; ++i) perm[i] = pv[(size_t)i];
     if (info) {
         info[0] = (double)oi.nnz_pattern; info[1] = (double)oi.nnz_factor; info[2] = oi.flops; info[3] = (double)oi.height;
-        // the panel tree the device would walk (same analysis as ipm_set_A_csc runs): what a cost model needs
-        std::vector<int> pos((size_t)m), pcp((size_t)n + 1, 0), pri((size_t)colptr[n]);
-        for (int64_t k = 0; k < m; ++k) pos[(size_t)pv[(size_t)k]] = (int)k;
-        for (int64_t j = 0; j < n; ++j) {
-            for (int32_t q = colptr[j]; q < colptr[j + 1]; ++q) pri[(size_t)q] = pos[(size_t)rowind[q]];
-            pcp[(size_t)j + 1] = colptr[j + 1];
-        }
-        sym::Pattern P;
+        // the panel tree the device would walk (the analysis ipm_set_A_csc needs for the rows in this order): what a cost model
+        // needs.  Kept for that call (sym_cache): the caller permutes the rows and hands the matrix over next.
         sym::Supernodes S;
         double relax = 1.0;
         if (const char* e = getenv("IPM_SP_RELAX")) relax = atof(e);
-        if (sym::normal_pattern((int)m, (int)n, pcp.data(), pri.data(), (int64_t)1.5e8, P) &&
-            sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax) == 0) {
+        if ((int64_t)P.idx.size() <= (int64_t)1.5e8 && sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax) == 0) {
             double area = 0.0; int levels = 0;
             sym::critical_path(S, area, levels);
             info[4] = (double)S.height; info[5] = area; info[6] = (double)S.nsn; info[7] = (double)S.rmax;
+            SymCacheEntry e;
+            e.m = (int)m; e.n = (int)n; e.relax = relax;
+            std::vector<int> pos((size_t)m);
+            for (int64_t k = 0; k < m; ++k) pos[(size_t)pv[(size_t)k]] = (int)k;
+            e.cp.assign(colptr, colptr + n + 1);
+            e.ri.resize((size_t)colptr[n]);
+            for (int64_t j = 0; j < n; ++j) {
+                for (int32_t q = colptr[j]; q < colptr[j + 1]; ++q) e.ri[(size_t)q] = pos[(size_t)rowind[q]];
+                std::sort(e.ri.begin() + colptr[j], e.ri.begin() + colptr[j + 1]);
+            }
+            e.S = std::move(S);
+            std::lock_guard<std::mutex> lock(g_sym_mutex);
+            if (g_sym_cache.size() >= 8) g_sym_cache.pop_front();
+            g_sym_cache.push_back(std::move(e));
         }
     }
     return IPM_OK;
@@ -1538,10 +1543,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             else if (h->bulk_variant == 3) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // 8 waves per tile
             else if (h->bulk_variant == 4) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
             else if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // the generic kernel (rounds 1-2)
-            else if (!h->upd_order_off.empty() && h->upd_order_off[(size_t)nt] >= 0) {
-                ub.tile_order = h->d_upd_order + h->upd_order_off[(size_t)nt];          // the table leaves tile (0,0) out itself
-                HIP_TRY(h, launch_chol_update(ub, sb, 0, nt * (nt + 1) / 2 - 1));
-            } else HIP_TRY(h, launch_chol_update(ub, sb, /*skip_first=*/1));
+            else HIP_TRY(h, launch_chol_update(ub, sb, /*skip_first=*/1));
         }
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }

@@ -197,8 +197,9 @@ struct OrderInfo {
 // Fill-reducing row order of A for the Cholesky of A D^2 A^T: minimum degree, then the elimination-tree postorder (subtrees
 // contiguous, parent after child).  perm[new] = old.  Returns 0, or 1 when the pattern or the work exceeds the caps
 // (the caller then keeps its dense/envelope path).
+// keep (optional): receives the pattern of A A^T IN THE FINAL ORDER, so that a caller who analyses next does not form it again.
 inline int order_rows(int m, int n, const int* cp, const int* ri, std::vector<int>& perm, OrderInfo& info,
-                      int64_t pattern_cap = (int64_t)6e7) {
+                      int64_t pattern_cap = (int64_t)6e7, Pattern* keep = nullptr) {
     Pattern P, Q;
     if (!normal_pattern(m, n, cp, ri, pattern_cap, P)) return 1;
     std::vector<int> order, parent, post;
@@ -232,6 +233,7 @@ inline int order_rows(int m, int n, const int* cp, const int* ri, std::vector<in
         info.height = std::max(info.height, hgt[k]);
         if (info.nnz_factor > (int64_t)2e8) return 1;
     }
+    if (keep) *keep = std::move(Q);
     return 0;
 }
 

@@ -6,20 +6,24 @@
 // factorization is a latency chain of 32 x (potrf_diag + two small GEMMs) that keeps a handful of CUs busy.  Two things are
 // needed to overlap them: whole CUs that the chain kernels can always get, and a way to run the bulk
 // matrix work of the factorization (panel solves, trailing updates) with low latency while the formation saturates the chip.
-//   * CUs: this kernel's workgroups take 136 KB of LDS, so exactly one fits a CU, and it is launched with FEWER workgroups
-//     than the chip has CUs (248 of 256): the remaining CUs stay empty for potrf_diag (133 KB of LDS) and the two critical
-//     GEMMs of every step, which run there at their solo pace (profiles/r02_reserve_probe.log).  No CU mask involved.
+//   * CUs: this kernel's workgroups take 139 KB of LDS, so exactly one fits a CU, and it is launched with FEWER workgroups
+//     than the chip has CUs -- 224 of 256: workgroups are dealt to the XCDs and shader engines in a fixed rotation whatever
+//     is free, so EVERY shader engine (8 XCDs x 4) must keep one CU empty, or a chain kernel's workgroup can wait for ever
+//     behind persistent workers (tools/ff_reserve_probe.hip; 248 / 240 / 232 workers ran into the spin bound).  potrf_diag
+//     (133 KB of LDS) and the two critical GEMMs of every step run on the empty CUs at their solo pace.  No CU mask involved.
 //   * Bulk work: the workgroups are WORKERS that draw items from one ordered list (ff_schedule.h): formation chunks
-//     (K = n / Q of one 128 x 128 tile, partial sums to a slab) interleaved with update / panel-solve items of the
+//     (a K range of a 256 x 128 PAIR of tiles, partial sums to slabs) interleaved with update / panel-solve items of the
 //     factorization, ordered so that what the chain needs next is always served first.  Formation commutes with the
 //     updates (tile = sum of slabs - sum_j L_ij L_cj^T), so the trailing updates do not wait for the formation.
 // Hand-offs between workers, and between workers and the chain kernels (other stream), are device counters under the
 // agent-scope release / acquire protocol of gemm_nt_f64.h; every spin is bounded (time-out word -> the host rolls the call
 // back and repeats it on the serial path).
 //
-// GEMM core: one 512-thread workgroup per 128 x 128 tile, 8 waves as 2 (M) x 4 (N), each wave 64 x 32 =
-// 4 x 2 tiles of v_mfma_f64_16x16x4_f64; BK = 32 stages, operands global -> registers -> LDS (rows padded to 34 doubles:
-// conflict-free ds_read_b64 fragment reads), double buffered, one barrier per stage.
+// GEMM engines (8 waves, v_mfma_f64_16x16x4_f64): ff_gemm_pair for the formation -- 256 x 128 per workgroup, waves 4 (M) x 2 (N),
+// BK = 16 stages on the schedule of adat_syrk_kernel (0.87 of the fp64 MFMA peak standalone, tools/ff_gemm_bench.hip);
+// ff_gemm_pipe for the updates -- 128 x 128, waves 2 x 4, BK = 32, software pipelined; ff_gemm for the panel product with P
+// taken from the accumulators through LDS.  Operands global -> registers -> LDS (rows padded: conflict-free ds_read_b64
+// fragment reads), double buffered, one barrier per stage.  DESIGN.md 4-F has the measurements and the rejected variants.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -27,6 +27,7 @@ done
 cd $R
 python tools/prof_db_stats.py $O/f_trace 16 > $O/f_kernel_stats.txt; head -12 $O/f_kernel_stats.txt | cut -c1-150
 python tools/pmc_form_kernel.py --kernel form_factor_kernel --out $O/f_pmc_form_kernel.json --shape 4096 8192 $O/f_pmc_* | tail -12
+cp $O/f_pmc_form_kernel.json profiles/r03_pmc_form_kernel_fused.json
 python - <<'PY'
 import glob, sqlite3
 db = glob.glob("gpurun_out/f_trace/**/*.db", recursive=True)[0]
@@ -50,3 +51,8 @@ timeout -k 10 400 python bench.py --m 16384 --n 32768 --steps 5 --warmup 1 --no-
 python -c "
 import json
 d=json.loads(open('gpurun_out/f_dense16k.json').read().strip().splitlines()[-1]); print('16k', d['value'], d['roofline']['frac'], d['roofline']['traffic_source'], d['objective_check'])"
+# the default line once more, now that the PMC pass of THIS kernel source is in profiles/ (roofline.traffic)
+timeout -k 10 600 python bench.py > $O/f_bench_final.json 2> $O/f_bench_final.err || { tail -20 $O/f_bench_final.err; exit 1; }
+python -c "
+import json
+d=json.loads(open('gpurun_out/f_bench_final.json').read().strip().splitlines()[-1]); print('final', round(d['value'],2), d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['traffic_source'], d['objective_check'], round(d['netlib_all']['value'],2), round(d['netlib']['value'],2))"

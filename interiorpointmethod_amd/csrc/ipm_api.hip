@@ -902,6 +902,20 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
 extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[8]) {
     if (m <= 0 || n <= 0 || !colptr || !rowind || !perm || m > (1 << 24)) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: bad arguments");
     for (int64_t i = 0; i < m; ++i) perm[i] = (int32_t)i;
+    // info[0] on input (optional, > 0): the ms per iteration the caller's alternative (the dense-tile path) is predicted to take.
+    // The elimination then stops early (IPM_ERR_WORKSPACE, as for a pattern that fills to dense) at the first pivot whose degree d
+    // shows that the sparse factor cannot win: the fronts on the way from that pivot to the root have d, d - 32, d - 64 ... rows,
+    // i.e. at least d^3 / 96 row^2 on the critical path at 5.56e-6 ms each (the fit of DESIGN 4-S), and a 10 % gain is asked for.
+    // The work budget of the elimination shrinks with it: on the 73 Netlib files every LP that ends on the sparse factor is ordered
+    // within 1.2e7 units of work (CZPROB), while the ones that fill up burn the full 6e7 (0.1 - 0.27 s of host time each) before
+    // they give up -- 2e7 + 4e6 per ms of the alternative keeps a 2x margin for an LP of a millisecond per iteration and the full
+    // budget for STOCFOR3-sized ones (10 ms).
+    int degree_cap = 0;
+    int64_t work_budget = (int64_t)6e7;
+    if (info && info[0] > 0.0 && info[0] < 1e6) {
+        degree_cap = std::max(64, (int)std::cbrt(info[0] * 96.0 / 5.56e-6 / 1.1));
+        work_budget = std::min<int64_t>(work_budget, (int64_t)(2e7 + 4e6 * info[0]));
+    }
     if (info) for (int k = 0; k < 8; ++k) info[k] = 0.0;
     if (colptr[0] != 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: colptr[0] != 0");
     for (int64_t j = 0; j < n; ++j) {
@@ -912,7 +926,7 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
     std::vector<int> pv;
     sym::OrderInfo oi;
     sym::Pattern P;                    // pattern of A A^T in the final order: formed once per LP, reused by the analysis below
-    if (sym::order_rows((int)m, (int)n, colptr, rowind, pv, oi, (int64_t)6e7, &P)) return fail(nullptr, IPM_ERR_WORKSPACE, "ipm_order_rows: A A^T is too dense for the sparse factor");
+    if (sym::order_rows((int)m, (int)n, colptr, rowind, pv, oi, (int64_t)6e7, &P, degree_cap, work_budget)) return fail(nullptr, IPM_ERR_WORKSPACE, "ipm_order_rows: A A^T is too dense for the sparse factor");
     for (int64_t i = 0; i < m; ++i) perm[i] = pv[(size_t)i];
     if (info) {
         info[0] = (double)oi.nnz_pattern; info[1] = (double)oi.nnz_factor; info[2] = oi.flops; info[3] = (double)oi.height;

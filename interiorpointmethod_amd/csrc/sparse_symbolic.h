@@ -13,6 +13,8 @@
 //   analyse          column structures by child merging, fundamental supernodes cut into panels that fit the LDS budget of
 //                    the numeric kernel, child lists, child -> parent inverse maps, slot of every entry of B in the panels
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <cstdint>
 #include <queue>
@@ -60,8 +62,10 @@ inline bool normal_pattern(int m, int n, const int* cp, const int* ri, int64_t c
     return true;
 }
 
-// order[k] = vertex eliminated k-th.  `budget` bounds the work (adjacency entries scanned); returns false when exceeded.
-inline bool min_degree(const Pattern& P, std::vector<int>& order, int64_t budget = (int64_t)6e7) {
+// order[k] = vertex eliminated k-th.  `budget` bounds the work (adjacency entries scanned); returns false when exceeded, or
+// (degree_cap > 0) as soon as a pivot of more than degree_cap neighbours comes up: every order of the rest then has a chain of
+// fronts of about degree_cap, degree_cap - w, ... rows up to the root, which the caller has decided it does not want.
+inline bool min_degree(const Pattern& P, std::vector<int>& order, int64_t budget = (int64_t)6e7, int degree_cap = 0, int64_t* work_out = nullptr) {
     const int m = P.m;
     std::vector<std::vector<int>> adjv((size_t)m), adje((size_t)m), elem((size_t)m);
     std::vector<char> state((size_t)m, 0);               // 0 variable, 1 element, 2 absorbed element
@@ -83,6 +87,7 @@ inline bool min_degree(const Pattern& P, std::vector<int>& order, int64_t budget
             if (state[t.second] == 0 && deg[t.second] == t.first) { p = t.second; break; }
         }
         if (p < 0) return false;                           // (cannot happen: every live variable has a current entry)
+        if (degree_cap > 0 && deg[p] > degree_cap) { if (work_out) *work_out = work; return false; }
         order.push_back(p);
         // reach of p: live variable neighbours + live members of its elements
         ++stamp; Lp.clear(); mark[p] = stamp;
@@ -131,8 +136,9 @@ inline bool min_degree(const Pattern& P, std::vector<int>& order, int64_t budget
             pq.push(DI(d, i));
         }
         // the marks of Lp were overwritten by the degree passes: nothing below relies on them
-        if (work > budget) return false;
+        if (work > budget) { if (work_out) *work_out = work; return false; }
     }
+    if (work_out) *work_out = work;
     return true;
 }
 
@@ -199,11 +205,14 @@ struct OrderInfo {
 // (the caller then keeps its dense/envelope path).
 // keep (optional): receives the pattern of A A^T IN THE FINAL ORDER, so that a caller who analyses next does not form it again.
 inline int order_rows(int m, int n, const int* cp, const int* ri, std::vector<int>& perm, OrderInfo& info,
-                      int64_t pattern_cap = (int64_t)6e7, Pattern* keep = nullptr) {
+                      int64_t pattern_cap = (int64_t)6e7, Pattern* keep = nullptr, int degree_cap = 0, int64_t work_budget = (int64_t)6e7) {
     Pattern P, Q;
     if (!normal_pattern(m, n, cp, ri, pattern_cap, P)) return 1;
     std::vector<int> order, parent, post;
-    if (!min_degree(P, order)) return 1;
+    int64_t md_work = 0;
+    const bool md_ok = min_degree(P, order, work_budget, degree_cap, &md_work);
+    if (getenv("IPM_ORDER_TRACE")) fprintf(stderr, "[order] m %d pattern %lld work %lld eliminated %zu %s\n", m, (long long)P.idx.size(), (long long)md_work, order.size(), md_ok ? "ok" : "gave up");
+    if (!md_ok) return 1;
     permute(P, order, Q);
     etree(Q, parent);
     postorder(parent, post);

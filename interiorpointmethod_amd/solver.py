@@ -67,15 +67,18 @@ def envelope_row_order(A, force=False):
     return None
 
 
-def sparse_factor_order(A):
+def sparse_factor_order(A, alternative_ms=0.0):
     """Fill-reducing row order for the multifrontal sparse Cholesky (ipm_order_rows: minimum degree + elimination-tree
     postorder, host only) -> (perm, info) with info = dict(nnz_pattern, nnz_factor, flops, height), or (None, None)
-    when A A^T is too dense for it.  The reference gets this from SuperLU's COLAMD inside spsolve (main.py:180)."""
+    when A A^T is too dense for it.  The reference gets this from SuperLU's COLAMD inside spsolve (main.py:180).
+    alternative_ms > 0: the predicted ms per iteration of the dense-tile path; the elimination then gives up (None, None)
+    at the first pivot whose degree shows that the sparse factor cannot beat it (factor="auto" passes it, "sparse" does not)."""
     lib = _lib.load()
     A = _sp.csc_matrix(A)
     m, n = A.shape
     perm = np.zeros(m, dtype=np.int32)
     info = np.zeros(8)
+    info[0] = float(alternative_ms)
     ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
     ii = np.ascontiguousarray(A.indices, dtype=np.int32)
     rc = lib.ipm_order_rows(m, n, ip.ctypes.data_as(C.POINTER(C.c_int32)), ii.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -106,8 +109,12 @@ def prefer_sparse_factor(m, info, dense_blocks):
     if info is None or m < SPARSE_FACTOR_MIN_ROWS or info.get("panel_height", 0) <= 0:
         return False
     t_sparse = max(0.3, -0.13 + 0.061 * info["panel_height"] + 5.56e-6 * info["path_area"])      # ms per iteration
-    t_dense = 0.1 + 0.08 * dense_blocks
-    return 1.1 * t_sparse < t_dense
+    return 1.1 * t_sparse < dense_tile_ms(dense_blocks)
+
+
+def dense_tile_ms(dense_blocks):
+    """Predicted ms per iteration of the dense-tile path (0.1 + 0.08 per 128-row block, fitted with the rule above)."""
+    return 0.1 + 0.08 * dense_blocks
 
 
 def _worth_ordering(A):
@@ -125,7 +132,7 @@ def path_flops(A, factor=None):
     factor = factor or os.environ.get("IPM_FACTOR", "auto")
     if _sp is not None and _sp.issparse(A) and factor != "dense" and m > FUSED_SMALL_MAX_ROWS and \
             (factor == "sparse" or (m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(_sp.csc_matrix(A)))):
-        perm, info = sparse_factor_order(A)
+        perm, info = sparse_factor_order(A, 0.0 if factor == "sparse" else dense_tile_ms((m + 127) // 128))
         if perm is not None and (factor == "sparse" or prefer_sparse_factor(m, info, (m + 127) // 128)):
             ORDER_INFO_CACHE[id(A)] = info
             return "sparse", float(info["flops"]), 4.0 * info["nnz_factor"]
@@ -201,7 +208,7 @@ class IpmSolver:
         self.order_info = None
         if _sp is not None and _sp.issparse(A) and factor != "dense" and \
                 (factor == "sparse" or (self.m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(A))):
-            perm, info = sparse_factor_order(A)
+            perm, info = sparse_factor_order(A, 0.0 if factor == "sparse" else dense_tile_ms((self.m + 127) // 128))
             if perm is not None and (factor == "sparse" or prefer_sparse_factor(self.m, info, (self.m + 127) // 128)):
                 self.factor, self.order_info = "sparse", info
                 self._perm = perm

@@ -526,7 +526,7 @@ def test_new_interior_sparse_general_form(golden_dir, name):
 # converge depends on summation orders: STANDATA converged in 190 iterations until round 2 regrouped the triangular solves
 # of small handles.  They stay listed so that the NEXT change of a summation order shows up here as a diff instead of
 # being curated out of the parity list above.
-GENERAL_EXPECTED_UNCONVERGED = {"STANDATA": 3, "SHELL": None, "SCAGR25": None}
+GENERAL_EXPECTED_UNCONVERGED = {"STANDATA": 3, "SHELL": 2, "SCAGR25": 3}    # round 3 (profiles/r03_general_form_unconverged_status.txt): NaN at 673, cap 999, NaN at 361
 
 
 @pytest.mark.parametrize("name", sorted(GENERAL_EXPECTED_UNCONVERGED))

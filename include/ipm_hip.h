@@ -198,8 +198,8 @@ int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32
  * updates of the last factorization that signalled a counter / recorded an event, out[6] = 1 when the tile envelope
  * of a sparse handle is exploited, out[7] = live handles on this device, out[8] = poll time-outs recovered so far,
  * out[9] = 1 when the fused single-workgroup small-LP path serves this handle, out[10] = 1 when the last iteration ran the
- * FUSED formation + factorization (one persistent launch beside the pivot chain; dense handles of 16 .. 96 blocks that
- * have the device to themselves), out[11] = 1 while a sparse-factor handle runs one launch per level of its panel tree
+ * FUSED formation + factorization (one persistent launch beside the pivot chain; dense handles of 20 .. 40 blocks with
+ * n <= 3 m that have the device to themselves), out[11] = 1 while a sparse-factor handle runs one launch per level of its panel tree
  * (shared device) instead of one launch per sweep.  (ABI 4: twelve words; ABI 3 had ten.) */
 int ipm_get_schedule(ipm_handle* h, int32_t out[12]);
 
@@ -211,7 +211,11 @@ int ipm_get_schedule(ipm_handle* h, int32_t out[12]);
  * elimination tree in columns; of the panel tree the device would walk (the analysis ipm_set_A_csc runs): [4] its height in
  * panels, [5] the largest sum of (front rows)^2 along a root-to-leaf path, [6] panels, [7] rows of the widest front
  * ([4..7] zero when that analysis exceeds its caps).  Returns IPM_OK; IPM_ERR_WORKSPACE when the pattern or the ordering work exceeds the
- * built-in caps (A A^T close to dense: keep the dense path), perm is then the identity. */
+ * built-in caps (A A^T close to dense: keep the dense path), perm is then the identity.
+ * info[0] ON INPUT (optional; 0 = off): the milliseconds per iteration the caller expects from its alternative, the dense-tile
+ * path.  The elimination then gives up early (IPM_ERR_WORKSPACE) once a pivot's degree shows that the sparse factor cannot
+ * beat that, and works within a budget scaled to it -- a caller that only wants the order when it pays (factor "auto" of the
+ * Python host) saves 40 % of the host time the hopeless cases cost. */
 int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[8]);
 /* Structure of the sparse factor of a handle created with IPM_FLAG_SPARSE_FACTOR (IPM_ERR_STATE otherwise):
  * out[0] panels, [1] tasks, [2] panel-tree height, [3] widest front (rows), [4] entries of L stored, [5] entries of the

@@ -220,14 +220,14 @@ def load_netlib(which, max_m=1 << 30):
 
 def predicted_ms_per_iteration(name, m):
     """The fitted per-iteration latency models of DESIGN.md 4-S (solver.prefer_sparse_factor): sparse multifrontal factor
-    0.061 ms per level of the panel tree + 5.56e-6 ms per (front rows)^2 along the critical path (floor 0.3 ms);
+    0.061 ms per level of the panel tree + 3.5e-6 ms per (front rows)^2 along the critical path (floor 0.3 ms);
     dense-tile factor 0.1 ms + 0.08 ms per 128-row block; the fused single-workgroup kernel (m <= 128) 0.02 ms."""
     from interiorpointmethod_amd.solver import FUSED_SMALL_MAX_ROWS
     if m <= FUSED_SMALL_MAX_ROWS:
         return 0.02
     info = ORDER_INFO.get(name)
     if PATHS.get(name) == "sparse" and info:
-        return max(0.3, -0.13 + 0.061 * info["panel_height"] + 5.56e-6 * info["path_area"])
+        return max(0.3, -0.13 + 0.061 * info["panel_height"] + 3.5e-6 * info["path_area"])
     return 0.1 + 0.08 * ((m + 127) // 128)
 
 
@@ -251,7 +251,7 @@ def netlib_roofline(names, probs, flops, rec, elapsed, world):
                     "wall / (78.6 TFLOP/s x GPUs); the suite is bound by dependent steps (pivot chain / elimination-tree "
                     "levels), not by flops",
             "latency_floor": {"model": "iterations x fitted ms per iteration, one LP at a time with the look-ahead (DESIGN 4-S: "
-                                       "sparse factor max(0.3, -0.13 + 0.061 panel-tree levels + 5.56e-6 critical-path area); "
+                                       "sparse factor max(0.3, -0.13 + 0.061 panel-tree levels + 3.5e-6 critical-path area); "
                                        "dense-tile factor 0.1 + 0.08 per 128-row block; fused small-LP kernel 0.02)",
                               "chain_seconds_one_gpu": float(per_lp_s.sum()),
                               "largest_lp_predicted_seconds": float(per_lp_s.max()) if len(per_lp_s) else 0.0,

@@ -867,7 +867,11 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     h->sp_nslot = nslot; h->sp_nu = S.uptr[nsn]; h->sp_height = S.height; h->sp_rmax = S.rmax; h->sp_nvirtual = S.nvirtual;
     h->sp_lds_doubles = (int)std::max<int64_t>(std::max<int64_t>(16, S.panel_max), std::min<int64_t>((int64_t)S.rmax * S.rmax, SPC_FRONT));
     if (const char* e = getenv("IPM_SP_FRONT")) h->sp_lds_doubles = (int)std::max<int64_t>(std::max<int64_t>(16, S.panel_max), std::min<int64_t>((int64_t)S.rmax * S.rmax, atoi(e)));
-    h->sp_lds_chol = sizeof(double) * (size_t)h->sp_lds_doubles;
+    {   // LDS of the factorization kernel: the largest panel image with its padded row stride (sparse_chol.h: sp_chol_lds_need)
+        long long need = 16;
+        for (int J = 0; J < nsn; ++J) need = std::max(need, sp_chol_lds_need((int)(S.rowptr[(size_t)J + 1] - S.rowptr[(size_t)J]), S.w[(size_t)J], h->sp_lds_doubles));
+        h->sp_lds_chol = sizeof(double) * (size_t)need;
+    }
     h->sp_lds_solve = sizeof(double) * ((size_t)std::max(16, S.rmax) + SPC_WCAP * SPC_WCAP);
     h->sp_threads = threads;
     if (h->sp_lds_solve > 48 * 1024 || h->sp_lds_chol > 48 * 1024) {
@@ -905,7 +909,7 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
     // info[0] on input (optional, > 0): the ms per iteration the caller's alternative (the dense-tile path) is predicted to take.
     // The elimination then stops early (IPM_ERR_WORKSPACE, as for a pattern that fills to dense) at the first pivot whose degree d
     // shows that the sparse factor cannot win: the fronts on the way from that pivot to the root have d, d - 32, d - 64 ... rows,
-    // i.e. at least d^3 / 96 row^2 on the critical path at 5.56e-6 ms each (the fit of DESIGN 4-S), and a 10 % gain is asked for.
+    // i.e. at least d^3 / 96 row^2 on the critical path at 3.5e-6 ms each (the fit of DESIGN 4-S), and a 10 % gain is asked for.
     // The work budget of the elimination shrinks with it: on the 73 Netlib files every LP that ends on the sparse factor is ordered
     // within 1.2e7 units of work (CZPROB), while the ones that fill up burn the full 6e7 (0.1 - 0.27 s of host time each) before
     // they give up -- 2e7 + 4e6 per ms of the alternative keeps a 2x margin for an LP of a millisecond per iteration and the full
@@ -913,7 +917,7 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
     int degree_cap = 0;
     int64_t work_budget = (int64_t)6e7;
     if (info && info[0] > 0.0 && info[0] < 1e6) {
-        degree_cap = std::max(64, (int)std::cbrt(info[0] * 96.0 / 5.56e-6 / 1.1));
+        degree_cap = std::max(64, (int)std::cbrt(info[0] * 96.0 / 3.5e-6 / 1.1));
         work_budget = std::min<int64_t>(work_budget, (int64_t)(2e7 + 4e6 * info[0]));
     }
     if (info) for (int k = 0; k < 8; ++k) info[k] = 0.0;

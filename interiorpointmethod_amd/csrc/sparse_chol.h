@@ -33,6 +33,18 @@ constexpr int SPC_BATCH = 8;             // independent entries a thread keeps i
 constexpr int SPC_FRONT = 4096;          // doubles of LDS a whole front may take (r <= 64)
 constexpr int SPC_WCAP = 32;             // columns per panel at most
 
+// LDS row stride (doubles) of a panel in sp_chol_kernel.  A whole FRONT (r x r) is read row against row by consecutive lanes in
+// its scalar update: an odd stride keeps those 64-bit reads on distinct banks (r = 32, 48, 64 ... would put every lane on the
+// same one).  A PANEL (r x w) feeds its update U -= L21 L21^T to the matrix cores: columns padded with zeros to a multiple of
+// four (one MFMA k-step) plus two -- stride = 2 mod 4, the 16 rows x 2 k of a half-wave's fragment read then fall on 32
+// distinct bank pairs (the rule of gemm_nt_f64.h).
+__host__ __device__ __forceinline__ int sp_front_stride(int r) { return r | 1; }
+__host__ __device__ __forceinline__ int sp_panel_stride(int w) { return ((w + 3) & ~3) + 2; }
+// doubles of LDS the factorization of one panel takes (front: r * r <= lds_front)
+__host__ __device__ __forceinline__ long long sp_chol_lds_need(int r, int w, long long lds_front) {
+    return (long long)r * r <= lds_front ? (long long)r * sp_front_stride(r) : (long long)r * sp_panel_stride(w);
+}
+
 struct SpNode {                          // one panel (64 bytes)
     int c0, w, r, nchild;
     int child0;                          // children: child[child0 .. child0 + nchild)
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
             const SpRec& rc = recs[tn];
             const int r = rc.r, w = rc.w, p = r - w, nchild = rc.nchild;
             const bool front = r * r <= lds;
-            const int ldp = front ? r : w;
+            const int ldp = front ? sp_front_stride(r) : sp_panel_stride(w);
             if (!level && rc.wait_children) {
                 if (tid < nchild && rc.ch[tid].ext) (void)sp_wait(flag + rc.ch[tid].K, epoch, f.timeout);   // (a time-out poisons the results; the host reruns the launch)
                 sp_consume_barrier<SC1>();
@@ -236,10 +248,15 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
             if (front) {
                 for (int idx = tid; idx < r * r; idx += NT) {
                     const int a = idx / r, b = idx - a * r;
-                    P[idx] = b < w ? Lp[a * w + b] : 0.0;
+                    P[a * ldp + b] = b < w ? Lp[a * w + b] : 0.0;
                 }
             } else {
-                for (int idx = tid; idx < r * w; idx += NT) P[idx] = Lp[idx];
+                // 32 column lanes x NT / 32 row groups; the pad columns w .. ldp - 3 are the zeros of the last MFMA k-step
+                const int bl = tid & 31, rg = tid >> 5;
+                for (int a = rg; a < r; a += NT / 32) {
+                    if (bl < w) P[a * ldp + bl] = Lp[a * w + bl];
+                    else if (bl < ldp - 2) P[a * ldp + bl] = 0.0;
+                }
                 if (kids) for (int idx = tid; idx < p * p; idx += NT) sp_st<SC1>(Up + idx, 0.0);
             }
             __syncthreads();
@@ -311,32 +328,48 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                 for (int idx = tid; idx < p * p; idx += NT) {
                     const int i = idx / p, j = idx - i * p;
                     if (j > i) continue;
-                    const double* ra = P + (w + i) * r;
-                    const double* rb = P + (w + j) * r;
+                    const double* ra = P + (w + i) * ldp;
+                    const double* rb = P + (w + j) * ldp;
                     double dot = 0.0;
                     for (int c = 0; c < w; ++c) dot += ra[c] * rb[c];
                     sp_st<SC1>(Up + idx, ra[w + j] - dot);
                 }
-            } else if (w > 0) {
-                for (int e0 = tid; e0 < p * p; e0 += SPC_BATCH * NT) {
-                    double old[SPC_BATCH];
-                    bool on[SPC_BATCH];
+            } else if (w > 0 && p > 0) {
+                // matrix cores: one 16 x 16 tile of U per wave pass, v_mfma_f64_16x16x4_f64 over the w columns (zero padded to a
+                // multiple of 4); operand fragments straight from the LDS panel.  Lane maps: gemm_nt_f64.h.
+                const int lane = tid & 63, wv = tid >> 6, fr = lane & 15, fk = lane >> 4;
+                const int nT = (p + 15) >> 4, ksteps = (w + 3) >> 2;
+                for (int t = wv; t < nT * (nT + 1) / 2; t += NT / 64) {
+                    int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                    while (I * (I + 1) / 2 > t) --I;
+                    const int J = t - I * (I + 1) / 2;
+                    const int ia = 16 * I + fr, jb = 16 * J + fr;
+                    const double* pa = P + (w + (ia < p ? ia : p - 1)) * ldp + fk;
+                    const double* pb = P + (w + (jb < p ? jb : p - 1)) * ldp + fk;
+                    const double ma = ia < p ? 1.0 : 0.0, mb = jb < p ? 1.0 : 0.0;      // rows beyond the front contribute zeros
+                    f64x4 acc0 = (f64x4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                    int kk = 0;
+                    for (; kk + 1 < ksteps; kk += 2) {
+                        const double a0 = pa[4 * kk] * ma, b0 = pb[4 * kk] * mb, a1 = pa[4 * kk + 4] * ma, b1 = pb[4 * kk + 4] * mb;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+                    }
+                    if (kk < ksteps) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk] * ma, pb[4 * kk] * mb, acc0, 0, 0, 0);
+                    // accumulator register q of lane l: U(16 I + (l >> 4) + 4 q, 16 J + (l & 15))
+                    const int j = 16 * J + fr;
+                    double old[4];
+                    bool on[4];
 #pragma unroll
-                    for (int k = 0; k < SPC_BATCH; ++k) {
-                        const int idx = e0 + k * NT;
-                        on[k] = idx < p * p && (idx % p) <= (idx / p);
-                        old[k] = (on[k] && kids) ? sp_ld<SC1>(Up + idx) : 0.0;
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * I + fk + 4 * q;
+                        on[q] = i < p && j <= i;
+                        old[q] = (on[q] && kids) ? sp_ld<SC1>(Up + (long long)i * p + j) : 0.0;
                     }
 #pragma unroll
-                    for (int k = 0; k < SPC_BATCH; ++k) {
-                        if (!on[k]) continue;
-                        const int idx = e0 + k * NT;
-                        const int i = idx / p, j = idx - i * p;
-                        const double* ra = P + (w + i) * w;
-                        const double* rb = P + (w + j) * w;
-                        double dot = 0.0;
-                        for (int c = 0; c < w; ++c) dot += ra[c] * rb[c];
-                        sp_st<SC1>(Up + idx, old[k] - dot);
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * I + fk + 4 * q;
+                        if (on[q]) sp_st<SC1>(Up + (long long)i * p + j, old[q] - (acc0[q] + acc1[q]));
                     }
                 }
             }

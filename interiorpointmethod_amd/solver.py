@@ -102,13 +102,14 @@ def prefer_sparse_factor(m, info, dense_blocks):
     0.57 / 0.92, SHELL 0.48 / 0.67, GFRD-PNC 0.36 / 0.65, SCTAP2 0.66 / 0.84, 80BAU3B 2.6 / 3.35, GANGES 1.01 / 1.13 -- but
     25FV47 1.34 / 0.70, NESM 2.85 / 1.77, GREENBEA 3.2 / 1.73, BNL2 4.4 / 1.62, D2Q06C 6.4 / 1.56, PILOTNOV 3.3 / 0.91, GROW15
     2.66 / 0.71.  The sparse factor walks the panel tree five times per iteration and every level is a hand-off between
-    workgroups: 0.061 ms per level of the panel tree plus 5.6e-6 ms per (front rows)^2 along the critical path (least
-    squares over 23 LPs, worst error 0.3 ms; info["panel_height"], info["path_area"] from ipm_order_rows).  The dense-tile
+    workgroups: 0.061 ms per level of the panel tree plus 3.5e-6 ms per (front rows)^2 along the critical path (round 2: least
+    squares over 23 LPs gave 5.6e-6, worst error 0.3 ms; round 3: the update of the large fronts moved to the matrix cores and
+    13 re-measured LPs give 2.6e-6 .. 5.3e-6, BNL2 4.4 -> 2.8, D2Q06C 6.4 -> 4.15, PILOTNOV 3.3 -> 2.3, 25FV47 1.34 -> 0.99 ms; info["panel_height"], info["path_area"] from ipm_order_rows).  The dense-tile
     path walks a chain of m/128 pivot blocks at 0.08 ms each and does its flops on the matrix cores.  A predicted gain of
     10 % switches paths: of the 23 measured LPs only SCFXM3 (0.54 / 0.63, predicted 0.86) is on the slower path."""
     if info is None or m < SPARSE_FACTOR_MIN_ROWS or info.get("panel_height", 0) <= 0:
         return False
-    t_sparse = max(0.3, -0.13 + 0.061 * info["panel_height"] + 5.56e-6 * info["path_area"])      # ms per iteration
+    t_sparse = max(0.3, -0.13 + 0.061 * info["panel_height"] + 3.5e-6 * info["path_area"])      # ms per iteration
     return 1.1 * t_sparse < dense_tile_ms(dense_blocks)
 
 

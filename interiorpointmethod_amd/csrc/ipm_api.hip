@@ -112,6 +112,9 @@ struct ipm_handle {
     long long sp_nslot = 0, sp_nu = 0, sp_terms = 0;
     int sp_height = 0, sp_rmax = 0, sp_grid = 1, sp_serial_launches = 0, sp_nvirtual = 0;
     size_t sp_lds_chol = 0, sp_lds_solve = 0;
+    int sp_fv_off = 0;                    // doubles of sp_chol_kernel's dynamic LDS in front of the forward substitution's r-vector
+    int sp_fuse_fwd = 1;                  // the predictor's forward substitution rides on the factorization (IPM_SP_FUSE_FWD=0: own sweep)
+    const double* sp_fwd_fused = nullptr; // right-hand side whose forward substitution the last factorization carried (z in t2)
     int sp_lds_doubles = 16, sp_threads = 256;
     int sp_level_mode = 0;                // 1 (IPM_SP_MODE=level): one launch per level of the panel tree, no in-kernel hand-offs; -1 (=task): one
                                           // launch per sweep even when the device is shared; 0: sp_level() decides
@@ -870,7 +873,9 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     {   // LDS of the factorization kernel: the largest panel image with its padded row stride (sparse_chol.h: sp_chol_lds_need)
         long long need = 16;
         for (int J = 0; J < nsn; ++J) need = std::max(need, sp_chol_lds_need((int)(S.rowptr[(size_t)J + 1] - S.rowptr[(size_t)J]), S.w[(size_t)J], h->sp_lds_doubles));
-        h->sp_lds_chol = sizeof(double) * (size_t)need;
+        h->sp_fv_off = (int)need;
+        h->sp_lds_chol = sizeof(double) * ((size_t)need + (size_t)std::max(16, S.rmax));      // + the r-vector of the fused forward substitution
+        if (const char* e = getenv("IPM_SP_FUSE_FWD")) h->sp_fuse_fwd = atoi(e);
     }
     h->sp_lds_solve = sizeof(double) * ((size_t)std::max(16, S.rmax) + SPC_WCAP * SPC_WCAP);
     h->sp_threads = threads;
@@ -1356,11 +1361,16 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
 //   bulk stream : [wait diag(k)] panel rows >= k+2 -> [wait crit(k)] rest of the trailing update
 // so the serial diagonal-block factorization of step k+1 overlaps the bulk update of step k.
 static int enqueue_group_inverses(ipm_handle* h, int g0, int g1, hipStream_t st);
-static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1, int ginv_step = -1) {
+// sp_fwd_rhs (sparse factor only): right-hand side whose forward substitution rides on the factorization (z -> h->t2); the next
+// enqueue_potrs of that right-hand side then runs the backward sweep only (h->sp_fwd_fused).
+static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1, int ginv_step = -1, const double* sp_fwd_rhs = nullptr) {
     if (sp_on(h)) {                     // multifrontal sparse Cholesky: one launch walks the elimination tree
+        if (!h->sp_fuse_fwd) sp_fwd_rhs = nullptr;
+        h->sp_fwd_fused = sp_fwd_rhs;
 #define SP_LAUNCH_CHOL(NT, SC, GRID, RECS, COUNT)                                                                                  \
     hipLaunchKernelGGL((sp_chol_kernel<NT, SC>), dim3(GRID), dim3(NT), h->sp_lds_chol, h->stream, h->spF, ep, &h->sc->maxdiag,       \
-                       h->opt.pivot_guard_eps, h->opt.pivot_guard_big, h->shift_rel, &h->sc->fixed, h->sp_lds_doubles, RECS, COUNT)
+                       h->opt.pivot_guard_eps, h->opt.pivot_guard_big, h->shift_rel, &h->sc->fixed, h->sp_lds_doubles, RECS, COUNT,    \
+                       sp_fwd_rhs, h->t2, h->sp_fv_off)
 #define SP_CHOL(GRID, RECS, COUNT)                                                                                                   \
     do {                                                                                                                             \
         if (h->sp_threads == 64) { if (h->sp_sc1) SP_LAUNCH_CHOL(64, true, GRID, RECS, COUNT); else SP_LAUNCH_CHOL(64, false, GRID, RECS, COUNT); } \
@@ -1876,8 +1886,10 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
     } while (0)
         unsigned ep = ++h->sp_epoch;
         const size_t nlev = h->sp_lvlptr.size() > 0 ? h->sp_lvlptr.size() - 1 : 0;
+        const bool fwd_done = h->sp_fwd_fused != nullptr && h->sp_fwd_fused == r;       // the factorization carried L z = r already (z in t2)
+        h->sp_fwd_fused = nullptr;
         if (sp_level(h)) {
-            for (size_t l = 0; l < nlev; ++l) {
+            for (size_t l = 0; l < nlev && !fwd_done; ++l) {
                 const int cnt = h->sp_lvlptr[l + 1] - h->sp_lvlptr[l];
                 SP_SWEEP(SP_LAUNCH_FWD, (unsigned)std::min(cnt, h->sp_grid), h->sp_rec_level + h->sp_lvlptr[l], cnt);
             }
@@ -1886,7 +1898,7 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
                 SP_SWEEP(SP_LAUNCH_BWD, (unsigned)std::min(cnt, h->sp_grid), h->sp_rec_level + h->sp_lvlptr[l], cnt);
             }
         } else {
-            SP_SWEEP(SP_LAUNCH_FWD, sp_launch_grid(h), h->spF.rec, 0);
+            if (!fwd_done) SP_SWEEP(SP_LAUNCH_FWD, sp_launch_grid(h), h->spF.rec, 0);
             ep = ++h->sp_epoch;
             SP_SWEEP(SP_LAUNCH_BWD, sp_launch_grid(h), h->spF.rec, 0);
         }
@@ -2031,6 +2043,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     if (all) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     if ((rc = enqueue_residuals(h))) return rc;
     h->ff_last = false;
+    bool have_rhs = false;
     if (ff_ok(h) && h->profiling < 2) {
         // (handles below 16 blocks have no residual stream: the fused launch is used here only when IPM_FUSED_FACTOR=force
         //  lowers the block limit -- the tests' way to run the fused kernels at small sizes)
@@ -2039,11 +2052,17 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         if ((rc = enqueue_form(h, h->d))) return rc;
         if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
-        if ((rc = enqueue_factor(h, true))) return rc;
+        if (sp_on(h) && h->sp_fuse_fwd) {
+            // sparse factor: the predictor's right-hand side does not depend on the factor -- form it first and let its forward
+            // substitution ride on the factorization (four walks of the elimination tree per iteration instead of five)
+            launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);   // rhs = -r_b - A (d*t)
+            have_rhs = true;
+            if ((rc = enqueue_factor(h, true, -1, -1, h->t1))) return rc;
+        } else if ((rc = enqueue_factor(h, true))) return rc;
     }
     if ((rc = enqueue_group_inverses(h))) return rc;
     if (all) HIP_TRY(h, hipEventRecord(ev[3], h->stream));
-    if ((rc = enqueue_predictor(h, all ? ev + 4 : nullptr))) return rc;
+    if ((rc = enqueue_predictor(h, all ? ev + 4 : nullptr, have_rhs))) return rc;
     if ((rc = enqueue_corrector(h, all ? ev + 6 : nullptr))) return rc;
     if ((rc = enqueue_update(h))) return rc;
     if (all) HIP_TRY(h, hipEventRecord(ev[8], h->stream));

@@ -206,7 +206,11 @@ __global__ __launch_bounds__(256) void sp_maxdiag_kernel(const double* L, const 
 template <int NT, bool SC1>
 __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch, const double* maxdiag, double eps,
                                                               double big, double shift_rel, int* fixed, int lds,
-                                                              const SpRec* __restrict__ recs, int lvl_count) {
+                                                              const SpRec* __restrict__ recs, int lvl_count,
+                                                              const double* fwd_rhs, double* fwd_z, int fv_off) {
+    // fwd_rhs != nullptr: the forward substitution L z = fwd_rhs rides on the factorization -- both walk the tree leaves first,
+    // the panel is in LDS anyway, and the sweep's own pass (one hand-off per level of the tree) is saved.  Same arithmetic in
+    // the same order as sp_fwd_kernel (bitwise equal z).  fv_off: doubles of dynamic LDS in front of the r-vector it needs.
     // lvl_count > 0: LEVEL mode -- this launch owns the lvl_count panels recs[0 .. lvl_count) of one level of the tree (all
     // their children were finished by earlier launches): no task queue, no waits, no flags.  lvl_count == 0: the whole tree in
     // one launch (recs = f.rec in task order), tasks drawn from the counter, hand-offs through flags.
@@ -322,6 +326,56 @@ __global__ __launch_bounds__(NT) void sp_chol_kernel(SpFactor f, unsigned epoch,
                     if (a >= b) P[a * ldp + b] *= rs[b];               // diagonal: pivot / sqrt(pivot) = sqrt(pivot)
                 }
                 __syncthreads();
+            }
+            if (fwd_rhs) {
+                double* fv = P + fv_off;
+                double* uv = f.uvec + rc.rowptr;
+                for (int a = tid; a < r; a += NT) fv[a] = a < w ? fwd_rhs[rc.c0 + a] : 0.0;
+                double cu[SPC_MAXCH];
+                int cr[SPC_MAXCH];
+#pragma unroll
+                for (int t = 0; t < SPC_MAXCH; ++t) {
+                    cr[t] = -1; cu[t] = 0.0;
+                    if (t < nchild) {
+                        const int pc = rc.ch[t].pc;
+                        if (tid < pc) { cu[t] = sp_ld<SC1>(f.uvec + rc.ch[t].relptr + tid); cr[t] = f.crel[rc.ch[t].relptr + tid]; }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < SPC_MAXCH; ++t) {
+                    if (t < nchild) {
+                        if (cr[t] >= 0) fv[cr[t]] += cu[t];
+                        const int pc = rc.ch[t].pc;
+                        if (pc > NT) {
+                            const double* uc = f.uvec + rc.ch[t].relptr;
+                            const int* rel = f.crel + rc.ch[t].relptr;
+                            for (int i = NT + tid; i < pc; i += NT) fv[rel[i]] += sp_ld<SC1>(uc + i);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                }
+                if (tid < 64 && w > 0) {                      // w x w lower triangular solve in the registers of wave 0 (as sp_fwd_kernel)
+                    const int ln = tid < w ? tid : 0;
+                    double fa = fv[ln];
+                    const double di = rs[ln];
+                    for (int c = 0; c < w; ++c) {
+                        const double zc = readlane_f64(fa, c) * readlane_f64(di, c);
+                        if (tid == c) fa = zc;
+                        else if (tid > c && tid < w) fa -= P[tid * ldp + c] * zc;
+                    }
+                    if (tid < w) fv[tid] = fa;
+                }
+                __syncthreads();
+                for (int a = tid; a < r; a += NT) {
+                    if (a < w) { fwd_z[rc.c0 + a] = fv[a]; }
+                    else {
+                        const double* row = P + a * ldp;
+                        double dot = 0.0;
+                        for (int c = 0; c < w; ++c) dot += row[c] * fv[c];
+                        sp_st<SC1>(uv + a, fv[a] - dot);
+                    }
+                }
             }
             // ---- U = (children's sum) - L21 L21^T, panel to memory
             if (front) {

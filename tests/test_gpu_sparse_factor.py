@@ -100,6 +100,28 @@ def test_schedule_independence(golden_dir, monkeypatch):
         assert np.array_equal(z, out[0][0]) and np.array_equal(L, out[0][1])
 
 
+@pytest.mark.parametrize("name", ["STOCFOR2", "SCTAP3", "BNL2"])
+def test_forward_substitution_fused_into_the_factorization(golden_dir, monkeypatch, name):
+    """Inside the solve loop the predictor's forward substitution rides on the factorization (sp_chol_kernel with a right-hand
+    side: four walks of the elimination tree per iteration instead of five).  Same arithmetic in the same order as the
+    sweep's own kernel: the whole solve -- iteration count, objective, iterate -- is BITWISE the one of IPM_SP_FUSE_FWD=0, in
+    the one-launch-per-sweep mode and in the level-per-launch mode the batched suite runs."""
+    A, b, c = _lp(golden_dir, name)
+    for mode in ("task", "level"):
+        monkeypatch.setenv("IPM_SP_MODE", mode)
+        res = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("IPM_SP_FUSE_FWD", fuse)
+            with ipm.IpmSolver(A, b, c, factor="sparse") as sv:
+                sv.init_state(1.0)
+                st = sv.solve(tol=1e-8, max_iter=40)
+                res[fuse] = (st["iterations"], st["objective"], sv.get_state())
+        assert res["1"][0] == res["0"][0] and res["1"][0] > 5
+        assert res["1"][1] == res["0"][1] or (np.isnan(res["1"][1]) and np.isnan(res["0"][1]))
+        for u, v in zip(res["1"][2], res["0"][2]):
+            assert np.array_equal(u, v, equal_nan=True), (name, mode)
+
+
 def test_direction_seam_on_the_sparse_factor(golden_dir):
     """The reference's own predictor / corrector vectors (kat_BANDM.npz, generated from main.py:197-269) through the sparse
     factor, same bounds as test_gpu_parity.py::test_direction_kats."""

@@ -81,6 +81,9 @@ struct ipm_handle {
     int group_steps = 0;                  // > 0: forced group size of the two-level schedule
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
+    int ss_small_blocks = 16;             // single-stream handles: trailing blocks up to which the narrow-tile panel / update kernels are used (73-LP suite, 8 in flight:
+                                          // 12.4 / 13.5 / 14.1 / 14.5 / 14.4 LPs/s for 0 / 4 / 8 / 16 / 64 blocks)
+    int ss_tiny_blocks = 0;               // ... and up to which the update runs on 32 x 32 tiles (IPM_SS_TINY_TILES)
     int bulk_variant = 0;                 // 0: chol_update_kernel (adat_syrk schedule, round 3); 7: the generic kernel of rounds 1-2; 1: BK=32 tiles (measured slower: 2.38 vs 2.26 ms)
     int crit_variant = 1;                 // critical-path GEMMs: 1 = 32-row tiles of the generic kernel, 0 = its plain tiles,
                                           // 2 = single-stage register kernels (chol_crit_f64.h; measured SLOWER: their
@@ -517,6 +520,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
+    if (const char* e = getenv("IPM_SS_SMALL_TILES")) h->ss_small_blocks = atoi(e);
+    if (const char* e = getenv("IPM_SS_TINY_TILES")) h->ss_tiny_blocks = atoi(e);
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
@@ -1487,6 +1492,15 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         u.C = h->B + (int64_t)(k + 1) * NB * (h->mp + 1); u.ldc = h->mp; u.M = rem; u.N = rem; u.K = NB;
         u.alpha = -1.0; u.beta = 1.0; u.lower = 1; u.unit_diag_from = -1; u.done = done;
         if (!la) {
+            // one stream (batched mode, small handles): panel and update are BOTH on the dependent chain of the step.  With few
+            // trailing blocks the chip is empty anyway: narrower tiles (32-row panel strips on 8 waves / 64 x 64 update tiles) are
+            // latency-shorter kernels -- ss_small_blocks = trailing blocks up to which they are used (IPM_SS_SMALL_TILES)
+            if (rem <= h->ss_small_blocks * NB) {
+                HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(t, sm)));
+                if (rem <= h->ss_tiny_blocks * NB) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(u, sm)));
+                else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(u, sm)));
+                continue;
+            }
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(t, sm)));
             if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(u, sm)));
             else HIP_TRY(h, launch_chol_update(u, sm));

@@ -81,6 +81,9 @@ struct ipm_handle {
     int group_steps = 0;                  // > 0: forced group size of the two-level schedule
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
+    int trsv_multi = 0;                   // IPM_TRSV_MULTI=1: block-step substitutions four steps per launch (every workgroup recomputes the group's solution
+                                          // blocks: bitwise equal, a third of the launches -- and measured SLOWER in the batched suite, 14.25 vs 14.6 LPs/s: the
+                                          // recomputation is a chain of dependent 128 KB block loads per workgroup)
     int ss_small_blocks = 16;             // single-stream handles: trailing blocks up to which the narrow-tile panel / update kernels are used (73-LP suite, 8 in flight:
                                           // 12.4 / 13.5 / 14.1 / 14.5 / 14.4 LPs/s for 0 / 4 / 8 / 16 / 64 blocks)
     int ss_tiny_blocks = 0;               // ... and up to which the update runs on 32 x 32 tiles (IPM_SS_TINY_TILES)
@@ -521,6 +524,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
     if (const char* e = getenv("IPM_SS_SMALL_TILES")) h->ss_small_blocks = atoi(e);
+    if (const char* e = getenv("IPM_TRSV_MULTI")) h->trsv_multi = atoi(e);
     if (const char* e = getenv("IPM_SS_TINY_TILES")) h->ss_tiny_blocks = atoi(e);
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
@@ -1934,6 +1938,23 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
         hipLaunchKernelGGL(trsv_fwd_persistent_kernel, dim3(h->nblk), dim3(256), 0, h->stream, p);
         p.rhs = h->t2; p.z = out; p.flags = h->d_flags + h->nblk;
         hipLaunchKernelGGL(trsv_bwd_persistent_kernel, dim3(h->nblk), dim3(256), 0, h->stream, p);
+        HIP_TRY(h, hipGetLastError());
+        return IPM_OK;
+    }
+    if (h->trsv_multi && !h->use_env && h->nblk >= 2) {
+        // several block steps per launch, every workgroup recomputing the group's solution blocks for itself (no hand-offs)
+        TrsvMulti q;
+        q.L = h->B; q.ld = h->mp; q.inv = h->invD; q.done = &h->sc->done;
+        q.r = r; q.z = h->t2;
+        for (int k0 = 0; k0 < h->nblk; k0 += TRSV_MULTI_G) {
+            q.k0 = k0; q.g = std::min(TRSV_MULTI_G, h->nblk - k0);
+            hipLaunchKernelGGL(trsv_fwd_multi_kernel, dim3(h->nblk - k0), dim3(256), 0, h->stream, q);
+        }
+        q.r = h->t2; q.z = out;
+        for (int k0 = h->nblk - 1; k0 >= 0; k0 -= TRSV_MULTI_G) {
+            q.k0 = k0; q.g = std::min(TRSV_MULTI_G, k0 + 1);
+            hipLaunchKernelGGL(trsv_bwd_multi_kernel, dim3(k0 + 1), dim3(256), 0, h->stream, q);
+        }
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }

@@ -620,6 +620,102 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Several block steps per launch WITHOUT any hand-off between workgroups (round 3): a launch covers the `g` steps k0 ..
+// k0 + g - 1 (forward) and every workgroup recomputes the g solution blocks of that group for itself -- g products with the
+// block inverses and g (g - 1) / 2 with the off-diagonal blocks of the group, 128 x 128 each, streamed through registers with the
+// next block in flight -- before it eliminates them from its own block row.  The arithmetic per block row is the one of the
+// step kernels in the same order (bitwise equal results); what is saved is g - 1 of every g dependent launches: a substitution
+// of 9 blocks is 3 launches instead of 9.  Used where the grouped inverses do not apply (block count not a multiple of the
+// group size) and no tile envelope limits the rows of a step.
+struct TrsvMulti {
+    const double* L; int64_t ld;
+    const double* inv;
+    double* r;                       // running right-hand side (consumed)
+    double* z;                       // solution
+    int k0, g;                       // forward: steps k0 .. k0+g-1; backward: steps k0, k0-1 .. k0-g+1
+    const int* done;
+};
+constexpr int TRSV_MULTI_G = 4;
+
+// grid = nblk - k0: workgroup b owns block row i = k0 + b
+__global__ __launch_bounds__(256) void trsv_fwd_multi_kernel(TrsvMulti a) {
+    if (a.done && *a.done) return;
+    __shared__ double vs[NB], us[NB], zs[TRSV_MULTI_G][NB];
+    const int tid = threadIdx.x;
+    const int i = a.k0 + (int)blockIdx.x;
+    const int mine = i - a.k0;                            // < g: this workgroup's row is solution block `mine` of the group
+    const int need = mine < a.g ? mine + 1 : a.g;         // solution blocks this workgroup has to know
+    BlockRegs R;
+    for (int s = 0; s < need; ++s) {
+        const int k = a.k0 + s;
+        if (tid < NB) vs[tid] = a.r[(int64_t)k * NB + tid];
+        __syncthreads();
+        for (int t = 0; t < s; ++t) {                      // v_s = r_k - sum_{t < s} L(k, k0 + t) z_t, ascending t
+            block_load(R, a.L + (int64_t)k * NB * a.ld + (int64_t)(a.k0 + t) * NB, a.ld);
+            block_gemv_n(R, zs[t], us);
+            __syncthreads();
+            if (tid < NB) vs[tid] -= us[tid];
+            __syncthreads();
+        }
+        block_load(R, a.inv + (int64_t)k * NB * NB, NB);
+        block_gemv_n(R, vs, zs[s]);
+        __syncthreads();
+    }
+    if (mine < a.g) {
+        if (tid < NB) a.z[(int64_t)i * NB + tid] = zs[mine][tid];
+        return;
+    }
+    if (tid < NB) vs[tid] = a.r[(int64_t)i * NB + tid];
+    __syncthreads();
+    for (int s = 0; s < a.g; ++s) {                        // r_i -= L(i, k0 + s) z_s, ascending s
+        block_load(R, a.L + (int64_t)i * NB * a.ld + (int64_t)(a.k0 + s) * NB, a.ld);
+        block_gemv_n(R, zs[s], us);
+        __syncthreads();
+        if (tid < NB) vs[tid] -= us[tid];
+        __syncthreads();
+    }
+    if (tid < NB) a.r[(int64_t)i * NB + tid] = vs[tid];
+}
+
+// grid = k0 + 1: workgroup b owns block column j = b; steps k0, k0 - 1 .. k0 - g + 1 (descending)
+__global__ __launch_bounds__(256) void trsv_bwd_multi_kernel(TrsvMulti a) {
+    if (a.done && *a.done) return;
+    __shared__ double vs[NB], us[NB], ws[TRSV_MULTI_G][NB];
+    __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
+    const int tid = threadIdx.x;
+    const int j = (int)blockIdx.x;
+    const int mine = a.k0 - j;                            // < g: this workgroup's column is solution block `mine` of the group
+    const int need = mine < a.g ? mine + 1 : a.g;
+    BlockRegs R;
+    for (int s = 0; s < need; ++s) {
+        const int k = a.k0 - s;
+        if (tid < NB) vs[tid] = a.r[(int64_t)k * NB + tid];
+        __syncthreads();
+        for (int t = 0; t < s; ++t) {                      // v_s = r_k - sum_{t < s} L(k0 - t, k)^T w_t, ascending t
+            block_load(R, a.L + (int64_t)(a.k0 - t) * NB * a.ld + (int64_t)k * NB, a.ld);
+            block_gemv_t(R, ws[t], us, scratch);
+            if (tid < NB) vs[tid] -= us[tid];
+            __syncthreads();
+        }
+        block_load(R, a.inv + (int64_t)k * NB * NB, NB);
+        block_gemv_t(R, vs, ws[s], scratch);
+    }
+    if (mine < a.g) {
+        if (tid < NB) a.z[(int64_t)j * NB + tid] = ws[mine][tid];
+        return;
+    }
+    if (tid < NB) vs[tid] = a.r[(int64_t)j * NB + tid];
+    __syncthreads();
+    for (int s = 0; s < a.g; ++s) {                        // r_j -= L(k0 - s, j)^T w_s, ascending s
+        block_load(R, a.L + (int64_t)(a.k0 - s) * NB * a.ld + (int64_t)j * NB, a.ld);
+        block_gemv_t(R, ws[s], us, scratch);
+        if (tid < NB) vs[tid] -= us[tid];
+        __syncthreads();
+    }
+    if (tid < NB) a.r[(int64_t)j * NB + tid] = vs[tid];
+}
+
+// ------------------------------------------------------------------------------------------
 // Persistent triangular solves: ONE launch per substitution instead of one per block step.
 // Workgroup i owns block row i (forward) / block column j (backward); it consumes the solution
 // blocks z_k of the earlier steps as they are published and publishes its own.  Off the critical

@@ -606,6 +606,27 @@ def test_bulk_update_kernel_bit_identical_to_generic(monkeypatch):
         assert rel(L["0"], np.linalg.cholesky(B)) < 1e-11
 
 
+def test_multi_step_substitution_bit_identical_to_block_steps(monkeypatch):
+    """trsv_fwd/bwd_multi_kernel (four block steps per launch, every workgroup recomputing the group's solution blocks for itself;
+    csrc/potrf_f64.h) against the one-step-per-launch kernels (IPM_TRSV_MULTI=0): the same arithmetic per block row in the same
+    order, so the solutions must be bitwise equal -- block counts that are no multiple of the group size of the grouped inverses
+    (3, 5, 7, 9, 13 blocks) and, with IPM_GROUPED_TRSV=0, one that is (8)."""
+    rng = np.random.default_rng(44)
+    for m, grouped in ((300, "1"), (600, "1"), (850, "1"), (1100, "1"), (1600, "1"), (1024, "0")):
+        M = rng.standard_normal((m, m + 30))
+        B = M @ M.T + 0.5 * np.eye(m)
+        rhs = rng.standard_normal(m)
+        z = {}
+        for multi in ("1", "0"):
+            monkeypatch.setenv("IPM_TRSV_MULTI", multi)
+            monkeypatch.setenv("IPM_GROUPED_TRSV", grouped)
+            with ipm.IpmSolver(np.eye(m, 1), np.zeros(m), np.zeros(1)) as sv:
+                z[multi], nfix = sv.solve_linear(B, rhs)
+            assert nfix == 0
+        assert np.array_equal(z["1"], z["0"]), m
+        assert np.linalg.norm(B @ z["1"].ravel() - rhs) / np.linalg.norm(rhs) < 1e-10
+
+
 def test_normal_solve_entry(golden_dir):
     """ipm_normal_solve: (A diag(d) A^T) z = rhs with the handle's own A, dense and sparse, factor reuse."""
     rng = np.random.default_rng(8)

@@ -84,6 +84,9 @@ struct ipm_handle {
     int trsv_multi = 0;                   // IPM_TRSV_MULTI=1: block-step substitutions four steps per launch (every workgroup recomputes the group's solution
                                           // blocks: bitwise equal, a third of the launches -- and measured SLOWER in the batched suite, 14.25 vs 14.6 LPs/s: the
                                           // recomputation is a chain of dependent 128 KB block loads per workgroup)
+    int la_small_blocks = 0;              // look-ahead handles: trailing blocks up to which the bulk stream uses the narrow-tile kernels (IPM_LA_SMALL_TILES).
+                                          // Off: a lone LP is bound by its pivot chain, not by the bulk stream (DEGEN3 0.94, BNL2 1.63, 25FV47 0.70 ms per
+                                          // iteration for 0 / 8 / 16 / 32 blocks alike; PILOT87 2.34 -> 2.49 -> 2.67 at 16 / 32)
     int ss_small_blocks = 16;             // single-stream handles: trailing blocks up to which the narrow-tile panel / update kernels are used (73-LP suite, 8 in flight:
                                           // 12.4 / 13.5 / 14.1 / 14.5 / 14.4 LPs/s for 0 / 4 / 8 / 16 / 64 blocks)
     int ss_tiny_blocks = 0;               // ... and up to which the update runs on 32 x 32 tiles (IPM_SS_TINY_TILES)
@@ -524,6 +527,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
     if (const char* e = getenv("IPM_SS_SMALL_TILES")) h->ss_small_blocks = atoi(e);
+    if (const char* e = getenv("IPM_LA_SMALL_TILES")) h->la_small_blocks = atoi(e);
     if (const char* e = getenv("IPM_TRSV_MULTI")) h->trsv_multi = atoi(e);
     if (const char* e = getenv("IPM_SS_TINY_TILES")) h->ss_tiny_blocks = atoi(e);
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
@@ -1560,7 +1564,11 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         if (rem > NB) {
             GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
             if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = crit_regs ? NB / 16 : NB / 32; tb.timeout = h->d_flags + 2 * (size_t)h->nblk; }   // workgroups of the critical panel launch
-            HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
+            // few trailing blocks: the bulk side of a step is as long as the chain's (potrf + two small GEMMs); the narrow-tile
+            // kernels of the single-stream path shorten it (la_small_blocks, IPM_LA_SMALL_TILES)
+            const bool la_small = !grouped && rem <= h->la_small_blocks * NB;
+            if (la_small) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tb, sb)));
+            else HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
             const int nt = rem / NB;
             if (grp_inner) {
@@ -1574,6 +1582,15 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
                 else ++h->n_event_steps;
                 if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb)));
                 else HIP_TRY(h, launch_chol_update(ub, sb));
+                HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
+                continue;
+            }
+            if (la_small) {                                         // 64 x 64 tiles; the critical 128 x 128 tile = the first three of them
+                const int n64 = rem / 64;
+                const int wgs = n64 * (n64 + 1) / 2 - 3;
+                if (fs) { bulk_wgs[k] = (unsigned)wgs; ub.signal = h->d_bulk_done + k; ++h->n_counter_steps; }
+                else ++h->n_event_steps;
+                HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/3)));
                 HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
                 continue;
             }

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("names", nargs="+")
     ap.add_argument("--kernel", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-sparse", action="store_true")
     args = ap.parse_args()
     for nm in args.names:
         A, b, c, cTlb, valid = load_npz_problem(os.path.join(G, "netlib", nm + ".npz"))
@@ -50,7 +51,7 @@ def main():
             kernel_level(nm, A, b, c)
         e2e = os.path.join(G, "e2e_%s.npz" % nm)
         ref = float(np.load(e2e)["objective"]) if os.path.exists(e2e) else float("nan")
-        for factor in (("sparse",) if args.no_dense else ("sparse", "dense")):
+        for factor in (("sparse",) if args.no_dense else (("dense",) if args.no_sparse else ("sparse", "dense"))):
             t0 = time.time()
             x, y, s, info = ipm.solve_with_info(A, b, c, tol=1e-8, max_iter=300, factor=factor)
             wall = time.time() - t0

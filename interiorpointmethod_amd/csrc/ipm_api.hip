@@ -82,8 +82,9 @@ struct ipm_handle {
     int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
     int trsv_multi = 0;                   // IPM_TRSV_MULTI=1: block-step substitutions four steps per launch (every workgroup recomputes the group's solution
-                                          // blocks: bitwise equal, a third of the launches -- and measured SLOWER in the batched suite, 14.25 vs 14.6 LPs/s: the
-                                          // recomputation is a chain of dependent 128 KB block loads per workgroup)
+                                          // blocks, next block prefetched: bitwise equal, a third of the launches).  No gain: a step kernel is two block
+                                          // products (~6 us), the recomputation makes a 4-step launch 14 of them -- BNL2 1.556 / 1.549, FINNIS 0.440 / 0.479 ms
+                                          // per iteration on a single-stream handle, the batched suite within noise
     int la_small_blocks = 0;              // look-ahead handles: trailing blocks up to which the bulk stream uses the narrow-tile kernels (IPM_LA_SMALL_TILES).
                                           // Off: a lone LP is bound by its pivot chain, not by the bulk stream (DEGEN3 0.94, BNL2 1.63, 25FV47 0.70 ms per
                                           // iteration for 0 / 8 / 16 / 32 blocks alike; PILOT87 2.34 -> 2.49 -> 2.67 at 16 / 32)

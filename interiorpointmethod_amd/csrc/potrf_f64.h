@@ -637,6 +637,21 @@ struct TrsvMulti {
 };
 constexpr int TRSV_MULTI_G = 4;
 
+// The blocks a workgroup multiplies with, in order: for s = 0 .. need-1 the off-diagonal blocks (s, t), t < s, of the group and the
+// block inverse s; then, for a block row / column outside the group, its g blocks against the group.  Streamed through TWO
+// register images: the next block is in flight while the current one is multiplied (a block is 128 KB: ~1.5 us from L2).
+struct TrsvOp { int kind, s, t; };       // kind 0: off-diagonal (s, t) of the group; 1: inverse s; 2: own row/column against s; -1: end
+__device__ __forceinline__ TrsvOp trsv_next_op(TrsvOp o, int need, int g, bool outside) {
+    if (o.kind == 0) { if (o.t + 1 < o.s) return {0, o.s, o.t + 1}; return {1, o.s, 0}; }
+    if (o.kind == 1) {
+        if (o.s + 1 < need) return {0, o.s + 1, 0};
+        if (outside) return {2, 0, 0};
+        return {-1, 0, 0};
+    }
+    if (o.kind == 2 && o.s + 1 < g) return {2, o.s + 1, 0};
+    return {-1, 0, 0};
+}
+
 // grid = nblk - k0: workgroup b owns block row i = k0 + b
 __global__ __launch_bounds__(256) void trsv_fwd_multi_kernel(TrsvMulti a) {
     if (a.done && *a.done) return;
@@ -644,37 +659,47 @@ __global__ __launch_bounds__(256) void trsv_fwd_multi_kernel(TrsvMulti a) {
     const int tid = threadIdx.x;
     const int i = a.k0 + (int)blockIdx.x;
     const int mine = i - a.k0;                            // < g: this workgroup's row is solution block `mine` of the group
-    const int need = mine < a.g ? mine + 1 : a.g;         // solution blocks this workgroup has to know
-    BlockRegs R;
-    for (int s = 0; s < need; ++s) {
-        const int k = a.k0 + s;
-        if (tid < NB) vs[tid] = a.r[(int64_t)k * NB + tid];
-        __syncthreads();
-        for (int t = 0; t < s; ++t) {                      // v_s = r_k - sum_{t < s} L(k, k0 + t) z_t, ascending t
-            block_load(R, a.L + (int64_t)k * NB * a.ld + (int64_t)(a.k0 + t) * NB, a.ld);
-            block_gemv_n(R, zs[t], us);
+    const bool outside = mine >= a.g;
+    const int need = outside ? a.g : mine + 1;            // solution blocks this workgroup has to know
+    auto block_of = [&](TrsvOp o) -> const double* {
+        if (o.kind == 0) return a.L + (int64_t)(a.k0 + o.s) * NB * a.ld + (int64_t)(a.k0 + o.t) * NB;
+        if (o.kind == 1) return a.inv + (int64_t)(a.k0 + o.s) * NB * NB;
+        return a.L + (int64_t)i * NB * a.ld + (int64_t)(a.k0 + o.s) * NB;
+    };
+    auto ld_of = [&](TrsvOp o) -> int64_t { return o.kind == 1 ? (int64_t)NB : a.ld; };
+    // v = running right-hand side of the block being solved (global -> LDS at the start and after every inverse)
+    if (tid < NB) vs[tid] = a.r[(int64_t)a.k0 * NB + tid];
+    auto apply = [&](const BlockRegs& R, TrsvOp o) {
+        if (o.kind == 1) {                                 // z_s = inv(s) v ; then v = rhs of what comes next
+            block_gemv_n(R, vs, zs[o.s]);
+            __syncthreads();
+            const int nxt = o.s + 1 < need ? a.k0 + o.s + 1 : (outside ? i : -1);
+            if (nxt >= 0 && tid < NB) vs[tid] = a.r[(int64_t)nxt * NB + tid];
+            __syncthreads();
+        } else {                                           // v -= block z_t  (kind 0: t = o.t; kind 2: t = o.s)
+            block_gemv_n(R, zs[o.kind == 0 ? o.t : o.s], us);
             __syncthreads();
             if (tid < NB) vs[tid] -= us[tid];
             __syncthreads();
         }
-        block_load(R, a.inv + (int64_t)k * NB * NB, NB);
-        block_gemv_n(R, vs, zs[s]);
-        __syncthreads();
-    }
-    if (mine < a.g) {
-        if (tid < NB) a.z[(int64_t)i * NB + tid] = zs[mine][tid];
-        return;
-    }
-    if (tid < NB) vs[tid] = a.r[(int64_t)i * NB + tid];
+    };
+    BlockRegs RA, RB;
+    TrsvOp o = {1, 0, 0};                                  // s = 0 has no off-diagonal blocks
+    block_load(RA, block_of(o), ld_of(o));
     __syncthreads();
-    for (int s = 0; s < a.g; ++s) {                        // r_i -= L(i, k0 + s) z_s, ascending s
-        block_load(R, a.L + (int64_t)i * NB * a.ld + (int64_t)(a.k0 + s) * NB, a.ld);
-        block_gemv_n(R, zs[s], us);
-        __syncthreads();
-        if (tid < NB) vs[tid] -= us[tid];
-        __syncthreads();
+    for (;;) {
+        TrsvOp o2 = trsv_next_op(o, need, a.g, outside);
+        if (o2.kind >= 0) block_load(RB, block_of(o2), ld_of(o2));
+        apply(RA, o);
+        if (o2.kind < 0) break;
+        TrsvOp o3 = trsv_next_op(o2, need, a.g, outside);
+        if (o3.kind >= 0) block_load(RA, block_of(o3), ld_of(o3));
+        apply(RB, o2);
+        if (o3.kind < 0) break;
+        o = o3;
     }
-    if (tid < NB) a.r[(int64_t)i * NB + tid] = vs[tid];
+    if (!outside) { if (tid < NB) a.z[(int64_t)i * NB + tid] = zs[mine][tid]; }
+    else if (tid < NB) a.r[(int64_t)i * NB + tid] = vs[tid];
 }
 
 // grid = k0 + 1: workgroup b owns block column j = b; steps k0, k0 - 1 .. k0 - g + 1 (descending)
@@ -685,34 +710,44 @@ __global__ __launch_bounds__(256) void trsv_bwd_multi_kernel(TrsvMulti a) {
     const int tid = threadIdx.x;
     const int j = (int)blockIdx.x;
     const int mine = a.k0 - j;                            // < g: this workgroup's column is solution block `mine` of the group
-    const int need = mine < a.g ? mine + 1 : a.g;
-    BlockRegs R;
-    for (int s = 0; s < need; ++s) {
-        const int k = a.k0 - s;
-        if (tid < NB) vs[tid] = a.r[(int64_t)k * NB + tid];
-        __syncthreads();
-        for (int t = 0; t < s; ++t) {                      // v_s = r_k - sum_{t < s} L(k0 - t, k)^T w_t, ascending t
-            block_load(R, a.L + (int64_t)(a.k0 - t) * NB * a.ld + (int64_t)k * NB, a.ld);
-            block_gemv_t(R, ws[t], us, scratch);
+    const bool outside = mine >= a.g;
+    const int need = outside ? a.g : mine + 1;
+    auto block_of = [&](TrsvOp o) -> const double* {       // solution block s of the group is block row / column k0 - s
+        if (o.kind == 0) return a.L + (int64_t)(a.k0 - o.t) * NB * a.ld + (int64_t)(a.k0 - o.s) * NB;     // L(k0 - t, k0 - s)^T
+        if (o.kind == 1) return a.inv + (int64_t)(a.k0 - o.s) * NB * NB;
+        return a.L + (int64_t)(a.k0 - o.s) * NB * a.ld + (int64_t)j * NB;                                   // L(k0 - s, j)^T
+    };
+    auto ld_of = [&](TrsvOp o) -> int64_t { return o.kind == 1 ? (int64_t)NB : a.ld; };
+    if (tid < NB) vs[tid] = a.r[(int64_t)a.k0 * NB + tid];
+    auto apply = [&](const BlockRegs& R, TrsvOp o) {       // (block_gemv_t ends with a barrier)
+        if (o.kind == 1) {
+            block_gemv_t(R, vs, ws[o.s], scratch);
+            const int nxt = o.s + 1 < need ? a.k0 - o.s - 1 : (outside ? j : -1);
+            if (nxt >= 0 && tid < NB) vs[tid] = a.r[(int64_t)nxt * NB + tid];
+            __syncthreads();
+        } else {
+            block_gemv_t(R, ws[o.kind == 0 ? o.t : o.s], us, scratch);
             if (tid < NB) vs[tid] -= us[tid];
             __syncthreads();
         }
-        block_load(R, a.inv + (int64_t)k * NB * NB, NB);
-        block_gemv_t(R, vs, ws[s], scratch);
-    }
-    if (mine < a.g) {
-        if (tid < NB) a.z[(int64_t)j * NB + tid] = ws[mine][tid];
-        return;
-    }
-    if (tid < NB) vs[tid] = a.r[(int64_t)j * NB + tid];
+    };
+    BlockRegs RA, RB;
+    TrsvOp o = {1, 0, 0};
+    block_load(RA, block_of(o), ld_of(o));
     __syncthreads();
-    for (int s = 0; s < a.g; ++s) {                        // r_j -= L(k0 - s, j)^T w_s, ascending s
-        block_load(R, a.L + (int64_t)(a.k0 - s) * NB * a.ld + (int64_t)j * NB, a.ld);
-        block_gemv_t(R, ws[s], us, scratch);
-        if (tid < NB) vs[tid] -= us[tid];
-        __syncthreads();
+    for (;;) {
+        TrsvOp o2 = trsv_next_op(o, need, a.g, outside);
+        if (o2.kind >= 0) block_load(RB, block_of(o2), ld_of(o2));
+        apply(RA, o);
+        if (o2.kind < 0) break;
+        TrsvOp o3 = trsv_next_op(o2, need, a.g, outside);
+        if (o3.kind >= 0) block_load(RA, block_of(o3), ld_of(o3));
+        apply(RB, o2);
+        if (o3.kind < 0) break;
+        o = o3;
     }
-    if (tid < NB) a.r[(int64_t)j * NB + tid] = vs[tid];
+    if (!outside) { if (tid < NB) a.z[(int64_t)j * NB + tid] = ws[mine][tid]; }
+    else if (tid < NB) a.r[(int64_t)j * NB + tid] = vs[tid];
 }
 
 // ------------------------------------------------------------------------------------------

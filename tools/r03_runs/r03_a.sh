@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, first GPU call: the GPU test suite, the default bench line (now with netlib_all), BASELINE config 5's profiler
 # evidence (kernel trace + PMC passes at 16384 x 32768) and ONE profiled run of the batched 73-LP suite with the process'
-# address map dumped (to symbolise the round-2 abort if it shows again).   tools/r03_a.sh [skip_tests]
+# address map dumped (to symbolise the round-2 abort if it shows again).   tools/r03_runs/r03_a.sh [skip_tests]
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD

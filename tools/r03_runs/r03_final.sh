@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3 evidence run: GPU test suite, default bench line, kernel trace + PMC passes of the fused launch at the headline
-# size, its in-kernel cycle profile, the sizes sweep, config 5.   tools/r03_final.sh [skip_tests]
+# size, its in-kernel cycle profile, the sizes sweep, config 5.   tools/r03_runs/r03_final.sh [skip_tests]
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; O=$R/gpurun_out; mkdir -p $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3 evidence, second part: config 5 (16384 x 32768: bench line, kernel trace, PMC passes of adat_syrk_kernel with the
 # current kernel sources), the expected-status probe of the general-form files that do not converge from the reference's
-# start, and the batched 73-LP suite at 4 / 6 / 8 / 12 LPs in flight.      tools/r03_final2.sh
+# start, and the batched 73-LP suite at 4 / 6 / 8 / 12 LPs in flight.      tools/r03_runs/r03_final2.sh
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; O=$R/gpurun_out; mkdir -p $O

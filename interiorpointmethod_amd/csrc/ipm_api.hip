@@ -71,7 +71,7 @@ struct ipm_handle {
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
     int grouped_trsv = 1;                 // group inverses + GEMV solves (trsv_grouped.h); IPM_GROUPED_TRSV=0 disables
-    int gsz = 0;                          // 128-blocks per group: 8 from 16 blocks on, else the largest of 8/4/2 dividing nblk
+    int gsz = 0;                          // 128-blocks per group: 8 from 16 blocks on (ragged: leftover blocks are solved step by step), else the largest of 8/4/2 dividing nblk
     double *gXT = nullptr, *gX = nullptr, *gS = nullptr, *gPart = nullptr;   // own allocation
     int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
                                           // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
@@ -502,8 +502,16 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->no_dense) h->grouped_trsv = 0;      // the sparse factor has its own sweeps; a dense entry point on such a handle solves block by block
     h->gsz = 0;
     if (h->grouped_trsv) {
-        if (h->nblk >= 2 * GS_MAX) { if (h->nblk % GS_MAX == 0) h->gsz = GS_MAX; }
-        else for (int p2 = GS_MAX; p2 >= 2; p2 /= 2) if (h->nblk % p2 == 0) { h->gsz = p2; break; }
+        // RAGGED groups (round 3): the block count need not be a multiple of the group size -- floor(nblk / gsz) full groups get
+        // their explicit inverses, the blocks left over at the end are substituted block by block (enqueue_potrs_grouped).  From
+        // 16 blocks on always groups of 8 (19 blocks: 2 groups + 3 steps, 28 launches per iteration's four sweeps + 10 for the
+        // inverses instead of 76); 9 .. 15 blocks: the largest of 8 / 4 that divides, else 8 + leftover; below 9 as before.
+        const bool ragged = !(getenv("IPM_RAGGED_GROUPS") && atoi(getenv("IPM_RAGGED_GROUPS")) == 0);
+        if (h->nblk >= 2 * GS_MAX) { if (ragged || h->nblk % GS_MAX == 0) h->gsz = GS_MAX; }
+        else {
+            for (int p2 = GS_MAX; p2 >= 2; p2 /= 2) if (h->nblk % p2 == 0) { h->gsz = p2; break; }
+            if (ragged && h->nblk > GS_MAX && h->gsz < 4) h->gsz = GS_MAX;
+        }
         if (const char* e = getenv("IPM_GROUP_BLOCKS")) { const int v = atoi(e); if (v >= 2 && v <= GS_MAX && (v & (v - 1)) == 0 && h->nblk % v == 0) h->gsz = v; }
     }
     if (h->gsz > 0) {
@@ -1889,6 +1897,24 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out, hipEvent
             double* rb = r + (int64_t)(g + 1) * GR;
             launch_dense_gemv_n(h, h->B + (int64_t)(g + 1) * GR * h->mp + (int64_t)g * GR, h->mp, below, GR, z + (int64_t)g * GR, -1.0, 1.0,
                                 rb, rb);
+        }
+    }
+    // blocks behind the last full group (ragged groups): one launch per block step, as without groups
+    const int k_left = nG * GS;
+    if (k_left < h->nblk) {
+        TrsvStep a;
+        a.L = h->B; a.ld = h->mp; a.inv = h->invD; a.done = done;
+        a.r = r; a.z = z; a.j0 = 0;
+        for (int k = k_left; k < h->nblk; ++k) {
+            a.k = k;
+            const int nb = h->use_env ? h->env_last[k] - k + 1 : h->nblk - k;
+            hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb), dim3(256), 0, h->stream, a);
+        }
+        a.r = z; a.z = out;
+        for (int k = h->nblk - 1; k >= k_left; --k) {
+            a.k = k;
+            a.j0 = h->use_env ? h->env_first[k] : 0;
+            hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k - a.j0 + 1), dim3(256), 0, h->stream, a);
         }
     }
     for (int g = nG - 1; g >= 0; --g) {                                   // backward: L^T w = z

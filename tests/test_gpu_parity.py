@@ -868,16 +868,23 @@ def _check_lp_properties(A, b, c, st, x, y, s):
 
 def test_dense_6200x9000_default_two_level(monkeypatch):
     """49 blocks: the size from which the two-level Cholesky (groups of 3) is the DEFAULT schedule.  Same
-    iteration count and objective as the one-level factor (IPM_TWO_LEVEL=0) and the LP-level properties."""
+    iteration count and objective as the one-level factor (IPM_TWO_LEVEL=0) and the LP-level properties.  49 is no multiple
+    of the 8-block groups of the triangular solves: six full groups get their explicit inverses, the last block is solved as
+    a block step (ragged groups, round 3) -- same answer as the block-step substitutions alone (IPM_RAGGED_GROUPS=0)."""
     A, b, c = synthetic_lp(6200, 9000, seed=2)
     st, x, y, s, sched = _solve_checked(A, b, c)
-    assert sched["blocks"] == 49 and sched["group_steps"] == 3 and sched["grouped_trsv"] == 0
+    assert sched["blocks"] == 49 and sched["group_steps"] == 3 and sched["grouped_trsv"] == 1
     _check_lp_properties(A, b, c, st, x, y, s)
     monkeypatch.setenv("IPM_TWO_LEVEL", "0")
     st1, x1, _, _, sched1 = _solve_checked(A, b, c)
     assert sched1["group_steps"] == 1 and st1["iterations"] == st["iterations"]
     assert abs(st1["objective"] - st["objective"]) <= 1e-9 * max(1.0, abs(st["objective"]))
     assert rel(x, x1) < 1e-6
+    monkeypatch.delenv("IPM_TWO_LEVEL")
+    monkeypatch.setenv("IPM_RAGGED_GROUPS", "0")
+    st2, x2, _, _, sched2 = _solve_checked(A, b, c)
+    assert sched2["grouped_trsv"] == 0 and st2["iterations"] == st["iterations"]
+    assert abs(st2["objective"] - st["objective"]) <= 1e-9 * max(1.0, abs(st["objective"])) and rel(x, x2) < 1e-6
 
 
 def test_dense_16384x32768_config5(monkeypatch):

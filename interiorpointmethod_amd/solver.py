@@ -173,59 +173,82 @@ def _col(v, n, name):
     return v
 
 
+class Prepared:
+    """The host-side analysis of one LP -- what IpmSolver does before it touches the device: canonical A, the factorization
+    path (factor="auto" rule), the fill-reducing or envelope row order and A, b in that order.  `prepare` builds it and
+    IpmSolver(..., prepared=P) takes it.  (Computing it AHEAD of the solves on helper threads in the batched mode was tried and
+    is slower -- 14.55 -> 13.2 LPs/s on the 73-LP suite: the helpers' SciPy sections hold the interpreter lock the eight
+    worker threads need between their library calls.)"""
+    __slots__ = ("host", "A", "b", "c", "m", "n", "factor", "order_info", "perm")
+
+
+def prepare(A, b, c, dense=False, reorder="auto", factor=None):
+    """Host-only part of IpmSolver.__init__ (no device is touched) -> Prepared."""
+    P = Prepared()
+    P.perm = None
+    if _sp is not None and _sp.issparse(A):
+        A = _sp.csc_matrix(A, dtype=np.float64)
+        A.sum_duplicates()
+        A.sort_indices()
+        m, n = A.shape
+        if dense or A.nnz == 0:
+            A = np.ascontiguousarray(A.toarray())
+    else:
+        A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        if A.ndim != 2:
+            raise ValueError("A must be 2-D")
+        m, n = A.shape
+    P.m, P.n = int(m), int(n)
+    b = _col(b, P.m, "b")
+    c = _col(c, P.n, "c")
+    P.host = (A, b, c)
+    # factor: "dense" = blocked dense-tile Cholesky (tile envelope, RCM row order), "sparse" = multifrontal sparse
+    # Cholesky (minimum-degree row order), "auto" (default; environment IPM_FACTOR overrides) = whichever the model
+    # of prefer_sparse_factor expects to be faster
+    factor = factor or os.environ.get("IPM_FACTOR", "auto")
+    if factor not in ("auto", "dense", "sparse"):
+        raise ValueError("factor must be 'auto', 'dense' or 'sparse'")
+    P.factor, P.order_info = "dense", None
+    if _sp is not None and _sp.issparse(A) and factor != "dense" and \
+            (factor == "sparse" or (P.m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(A))):
+        perm, info = sparse_factor_order(A, 0.0 if factor == "sparse" else dense_tile_ms((P.m + 127) // 128))
+        if perm is not None and (factor == "sparse" or prefer_sparse_factor(P.m, info, (P.m + 127) // 128)):
+            P.factor, P.order_info = "sparse", info
+            P.perm = perm
+            A = _sp.csc_matrix(_sp.csr_matrix(A)[perm])
+            A.sort_indices()
+            b = np.ascontiguousarray(b[perm])
+        elif factor == "sparse":
+            raise ValueError("factor='sparse': A A^T is too dense for the sparse factor (ipm_order_rows)")
+    if P.factor == "dense" and _sp is not None and _sp.issparse(A) and reorder and \
+            (reorder == "rcm" or P.m >= REORDER_MIN_ROWS):
+        perm = envelope_row_order(A, force=(reorder == "rcm"))     # "auto": only when it pays
+        if perm is not None:
+            P.perm = perm
+            A = _sp.csc_matrix(_sp.csr_matrix(A)[perm])
+            A.sort_indices()
+            b = np.ascontiguousarray(b[perm])
+    P.A, P.b, P.c = A, b, c
+    return P
+
+
 class IpmSolver:
     """One LP bound to one GPU: owns a libipm_hip handle whose workspace is a torch tensor."""
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
                  check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto", concurrent=False,
-                 auto_regularize=True, factor=None):
+                 auto_regularize=True, factor=None, prepared=None):
         lib = _lib.load()
         self._lib = lib
         self._h = None
-        self._perm = None          # device row i = caller's row perm[i] (sparse A with a profitable RCM order only)
-        if _sp is not None and _sp.issparse(A):
-            A = _sp.csc_matrix(A, dtype=np.float64)
-            A.sum_duplicates()
-            A.sort_indices()
-            m, n = A.shape
-            if dense or A.nnz == 0:
-                A = np.ascontiguousarray(A.toarray())
-        else:
-            A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
-            if A.ndim != 2:
-                raise ValueError("A must be 2-D")
-            m, n = A.shape
-        self.m, self.n = int(m), int(n)
-        b = _col(b, self.m, "b")
-        c = _col(c, self.n, "c")
-        self._host = (A, b, c)      # caller's row order: used by start-point heuristics only
-        # factor: "dense" = blocked dense-tile Cholesky (tile envelope, RCM row order), "sparse" = multifrontal sparse
-        # Cholesky (minimum-degree row order), "auto" (default; environment IPM_FACTOR overrides) = whichever the model
-        # of prefer_sparse_factor expects to be faster
-        factor = factor or os.environ.get("IPM_FACTOR", "auto")
-        if factor not in ("auto", "dense", "sparse"):
-            raise ValueError("factor must be 'auto', 'dense' or 'sparse'")
-        self.factor = "dense"
-        self.order_info = None
-        if _sp is not None and _sp.issparse(A) and factor != "dense" and \
-                (factor == "sparse" or (self.m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(A))):
-            perm, info = sparse_factor_order(A, 0.0 if factor == "sparse" else dense_tile_ms((self.m + 127) // 128))
-            if perm is not None and (factor == "sparse" or prefer_sparse_factor(self.m, info, (self.m + 127) // 128)):
-                self.factor, self.order_info = "sparse", info
-                self._perm = perm
-                A = _sp.csc_matrix(_sp.csr_matrix(A)[perm])
-                A.sort_indices()
-                b = np.ascontiguousarray(b[perm])
-            elif factor == "sparse":
-                raise ValueError("factor='sparse': A A^T is too dense for the sparse factor (ipm_order_rows)")
-        if self.factor == "dense" and _sp is not None and _sp.issparse(A) and reorder and \
-                (reorder == "rcm" or self.m >= REORDER_MIN_ROWS):
-            perm = envelope_row_order(A, force=(reorder == "rcm"))     # "auto": only when it pays
-            if perm is not None:
-                self._perm = perm
-                A = _sp.csc_matrix(_sp.csr_matrix(A)[perm])
-                A.sort_indices()
-                b = np.ascontiguousarray(b[perm])
+        if prepared is None:
+            prepared = prepare(A, b, c, dense=dense, reorder=reorder, factor=factor)
+        # device row i = caller's row perm[i] (sparse A whose rows the host analysis reordered: minimum degree or RCM)
+        self._perm = prepared.perm
+        self.m, self.n = prepared.m, prepared.n
+        self._host = prepared.host  # caller's row order: used by start-point heuristics only
+        self.factor, self.order_info = prepared.factor, prepared.order_info
+        A, b, c = prepared.A, prepared.b, prepared.c
         opts = _lib.Options()
         lib.ipm_default_options(C.byref(opts))
         opts.eta, opts.pivot_guard_eps, opts.pivot_guard_big = eta, pivot_guard_eps, pivot_guard_big

@@ -145,3 +145,24 @@ def test_bench_netlib_helpers():
     t, why = B.load_traffic(4096, 8192)
     assert (t is None and ("stale" in why or "no PMC" in why or "shape" in why)) or t > 0
     assert len(B.kernel_source_sha()) == 16
+
+
+def test_prepare_is_host_only(golden_dir):
+    """solver.prepare -- the host analysis IpmSolver does before it touches the device: no device needed; STOCFOR2 goes to the
+    sparse factor with a minimum-degree row order, AFIRO (27 rows) stays dense and unpermuted, a dense ndarray passes through."""
+    from interiorpointmethod_amd import solver as S
+    probs = []
+    for nm in ("STOCFOR2", "AFIRO"):
+        A, b, c, cTlb, valid = matio.load_npz_problem(os.path.join(golden_dir, "netlib", nm + ".npz"))
+        probs.append((A, b, c))
+    probs.append(synthetic_lp(64, 128, seed=0))
+    P0, P1, P2 = (S.prepare(*p) for p in probs)
+    m0 = probs[0][0].shape[0]
+    assert P0.factor == "sparse" and sorted(P0.perm.tolist()) == list(range(m0)) and P0.order_info["nnz_factor"] > 0
+    assert sparse.issparse(P0.A) and P0.A.shape == probs[0][0].shape
+    assert np.array_equal(P0.b, np.asarray(probs[0][1], dtype=float).ravel()[P0.perm])
+    assert abs(P0.A - sparse.csr_matrix(sparse.csc_matrix(probs[0][0], dtype=float))[P0.perm]).sum() == 0
+    assert P1.factor == "dense" and P1.perm is None and (P1.m, P1.n) == (27, 51)
+    assert P2.factor == "dense" and isinstance(P2.A, np.ndarray) and P2.A.shape == (64, 128) and P2.perm is None
+    Q = S.prepare(*probs[0])
+    assert Q.factor == P0.factor and np.array_equal(Q.perm, P0.perm)         # deterministic

@@ -1315,9 +1315,9 @@ static inline unsigned sp_launch_grid(ipm_handle* h) {
 static int ensure_dense_B(ipm_handle* h) {
     if (h->B && h->invD) return IPM_OK;
     if (!h->no_dense) return fail(h, IPM_ERR_STATE, "handle has no dense normal-matrix buffer");
-    if (dev_malloc(h->device, h->stream, (void**)&h->B_own, sizeof(double) * (size_t)h->mp * h->mp) != hipSuccess ||
-        dev_malloc(h->device, h->stream, (void**)&h->invD_own, sizeof(double) * (size_t)h->nblk * NB * NB) != hipSuccess)
-        return fail(h, IPM_ERR_HIP, "dense normal-matrix buffer (%lld x %lld doubles) could not be allocated", (long long)h->mp, (long long)h->mp);
+    if ((!h->B_own && dev_malloc(h->device, h->stream, (void**)&h->B_own, sizeof(double) * (size_t)h->mp * h->mp) != hipSuccess) ||
+        (!h->invD_own && dev_malloc(h->device, h->stream, (void**)&h->invD_own, sizeof(double) * (size_t)h->nblk * NB * NB) != hipSuccess))
+        return fail(h, IPM_ERR_HIP, "dense normal-matrix buffer (%lld x %lld doubles) could not be allocated", (long long)h->mp, (long long)h->mp);   // (what was allocated stays owned: freed in ipm_destroy, reused by a later call)
     HIP_TRY(h, hipMemsetAsync(h->invD_own, 0, sizeof(double) * (size_t)h->nblk * NB * NB, h->stream));
     h->B = h->B_own; h->invD = h->invD_own;
     return IPM_OK;

@@ -212,8 +212,8 @@ int ipm_get_schedule(ipm_handle* h, int32_t out[12]);
  * panels, [5] the largest sum of (front rows)^2 along a root-to-leaf path, [6] panels, [7] rows of the widest front
  * ([4..7] zero when that analysis exceeds its caps).  Returns IPM_OK; IPM_ERR_WORKSPACE when the pattern or the ordering work exceeds the
  * built-in caps (A A^T close to dense: keep the dense path), perm is then the identity.
- * info[0] ON INPUT (optional; 0 = off): the milliseconds per iteration the caller expects from its alternative, the dense-tile
- * path.  The elimination then gives up early (IPM_ERR_WORKSPACE) once a pivot's degree shows that the sparse factor cannot
+ * info[0] ON INPUT, honoured only together with info[1] = -1.0 (so that an uninitialised array cannot switch it on): the
+ * milliseconds per iteration the caller expects from its alternative, the dense-tile path.  The elimination then gives up early (IPM_ERR_WORKSPACE) once a pivot's degree shows that the sparse factor cannot
  * beat that, and works within a budget scaled to it -- a caller that only wants the order when it pays (factor "auto" of the
  * Python host) saves 40 % of the host time the hopeless cases cost. */
 int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[8]);

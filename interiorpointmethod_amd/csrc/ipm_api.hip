@@ -933,7 +933,7 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
 extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowind, int32_t* perm, double info[8]) {
     if (m <= 0 || n <= 0 || !colptr || !rowind || !perm || m > (1 << 24)) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_order_rows: bad arguments");
     for (int64_t i = 0; i < m; ++i) perm[i] = (int32_t)i;
-    // info[0] on input (optional, > 0): the ms per iteration the caller's alternative (the dense-tile path) is predicted to take.
+    // info[0] on input (optional, > 0, with info[1] = -1 as the marker): the ms per iteration the caller's alternative (the dense-tile path) is predicted to take.
     // The elimination then stops early (IPM_ERR_WORKSPACE, as for a pattern that fills to dense) at the first pivot whose degree d
     // shows that the sparse factor cannot win: the fronts on the way from that pivot to the root have d, d - 32, d - 64 ... rows,
     // i.e. at least d^3 / 96 row^2 on the critical path at 3.5e-6 ms each (the fit of DESIGN 4-S), and a 10 % gain is asked for.
@@ -943,7 +943,7 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
     // budget for STOCFOR3-sized ones (10 ms).
     int degree_cap = 0;
     int64_t work_budget = (int64_t)6e7;
-    if (info && info[0] > 0.0 && info[0] < 1e6) {
+    if (info && info[1] == -1.0 && info[0] > 0.0 && info[0] < 1e6) {      // explicit opt-in (info[1] = -1): an uninitialised info array must not trigger it
         degree_cap = std::max(64, (int)std::cbrt(info[0] * 96.0 / 3.5e-6 / 1.1));
         work_budget = std::min<int64_t>(work_budget, (int64_t)(2e7 + 4e6 * info[0]));
     }

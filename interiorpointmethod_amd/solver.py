@@ -78,7 +78,8 @@ def sparse_factor_order(A, alternative_ms=0.0):
     m, n = A.shape
     perm = np.zeros(m, dtype=np.int32)
     info = np.zeros(8)
-    info[0] = float(alternative_ms)
+    if alternative_ms > 0.0:
+        info[0], info[1] = float(alternative_ms), -1.0     # (marker: include/ipm_hip.h)
     ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
     ii = np.ascontiguousarray(A.indices, dtype=np.int32)
     rc = lib.ipm_order_rows(m, n, ip.ctypes.data_as(C.POINTER(C.c_int32)), ii.ctypes.data_as(C.POINTER(C.c_int32)),

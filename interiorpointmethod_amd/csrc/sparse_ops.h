@@ -78,8 +78,19 @@ __global__ __launch_bounds__(256) void adat_list_kernel(const int* __restrict__ 
     if (done && *done) return;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < nb) {
+        // the terms in ascending order, eight at a time: all loads of a batch are issued before the first is used (the list of an
+        // entry is a chain of dependent loads otherwise: column index -> d), the sum itself stays sequential (same bits)
         double acc = 0.0;
-        for (int t = bptr[e]; t < bptr[e + 1]; ++t) {
+        const int t1 = bptr[e + 1];
+        int t = bptr[e];
+        for (; t + 8 <= t1; t += 8) {
+            double a_[8], k_[8], d_[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a_[u] = bai[t + u]; k_[u] = bak[t + u]; d_[u] = d[bcol[t + u]]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const double coef = a_[u] * d_[u]; acc += coef * k_[u]; }
+        }
+        for (; t < t1; ++t) {
             const double coef = bai[t] * d[bcol[t]];
             acc += coef * bak[t];
         }

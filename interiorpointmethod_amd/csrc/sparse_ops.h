@@ -36,14 +36,27 @@ __global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const doubl
     for (int k = tid; k < mp; k += 256) acc[k] = 0.0;
     __syncthreads();
     if (row < A.m) {
+        // what a nonzero needs before its column can be walked -- column index -> d_j and the column's extent -- is a chain of
+        // dependent loads; it is fetched for up to 256 nonzeros of the row AT ONCE (one per thread) into LDS, then the nonzeros
+        // are applied one after the other as before (fixed order: same bits)
+        __shared__ double s_coef[256];
+        __shared__ int s_qb[256], s_qe[256];
         const int pb = A.rowptr[row], pe = A.rowptr[row + 1];
-        for (int p = pb; p < pe; ++p) {                 // sequential over the row's nonzeros: fixed order
-            const int j = A.colind[p];
-            const double coef = A.rval[p] * d[j];
-            const int qb = A.colptr[j], qe = A.colptr[j + 1];
-            for (int q = qb + tid; q < qe; q += 256)    // distinct row indices within one column: no collisions
-                acc[A.rowind[q]] += coef * A.cval[q];
+        for (int p0 = pb; p0 < pe; p0 += 256) {
+            const int cnt = min(256, pe - p0);
+            if (tid < cnt) {
+                const int j = A.colind[p0 + tid];
+                s_coef[tid] = A.rval[p0 + tid] * d[j];
+                s_qb[tid] = A.colptr[j]; s_qe[tid] = A.colptr[j + 1];
+            }
             __syncthreads();
+            for (int u = 0; u < cnt; ++u) {             // sequential over the row's nonzeros: fixed order
+                const double coef = s_coef[u];
+                const int qe = s_qe[u];
+                for (int q = s_qb[u] + tid; q < qe; q += 256)    // distinct row indices within one column: no collisions
+                    acc[A.rowind[q]] += coef * A.cval[q];
+                __syncthreads();
+            }
         }
     } else if (tid == 0) {
         acc[row] = 1.0;

@@ -1385,6 +1385,14 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
 static int enqueue_group_inverses(ipm_handle* h, int g0, int g1, hipStream_t st);
 // sp_fwd_rhs (sparse factor only): right-hand side whose forward substitution rides on the factorization (z -> h->t2); the next
 // enqueue_potrs of that right-hand side then runs the backward sweep only (h->sp_fwd_fused).
+// 16-wide panels of diagonal block k that hold rows of the LP (the rest of the block is padding: unit diagonal): potrf_diag
+// factors only those -- the last real block of an LP whose row count is no multiple of 128, and the blocks the layout pads with
+static inline int potrf_panels(const ipm_handle* h, int k) {
+    if (h->shift_rel != 0.0) return NB / 16;              // (the Tikhonov shift touches every diagonal entry: keep the full block)
+    const int64_t real = h->m - (int64_t)k * NB;
+    return real >= NB ? NB / 16 : (int)std::max<int64_t>(1, (real + 15) / 16);
+}
+
 static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1, int ginv_step = -1, const double* sp_fwd_rhs = nullptr) {
     if (sp_on(h)) {                     // multifrontal sparse Cholesky: one launch walks the elimination tree
         if (!h->sp_fuse_fwd) sp_fwd_rhs = nullptr;
@@ -1472,6 +1480,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         pd.wait_on = nullptr; pd.wait_count = 0; pd.signal = nullptr; pd.timeout = nullptr; pd.dbg = nullptr; pd.dbg_tag = 0;
+        pd.nt = potrf_panels(h, k);
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
             hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
@@ -1773,6 +1782,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         pd.wait_on = dready + k; pd.wait_count = 10; pd.signal = potrfdone + k; pd.timeout = timeout; pd.dbg = dbg; pd.dbg_tag = (unsigned)k;
+        pd.nt = potrf_panels(h, k);
         hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         ++h->n_counter_steps;
         if (k == ginv_step) {

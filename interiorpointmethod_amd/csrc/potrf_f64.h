@@ -51,6 +51,8 @@ struct PotrfDiag {
     unsigned* signal;
     unsigned* timeout;
     unsigned* dbg; unsigned dbg_tag;   // diagnostic (may be null): see GemmNT::dbg; kind 7
+    int nt;                            // 16-wide panels to factor (1 .. 8): the rows from 16 nt on are PADDING rows (unit diagonal, nothing else):
+                                       // L and inv(L) are the identity there, exactly what factoring them gives, without the pivots
 };
 
 // sqrt(p) and 1/sqrt(p) from v_rsq_f64 (about 23 good bits) and one Halley step
@@ -431,9 +433,18 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
             if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
     }
+    const int nt = a.nt >= 1 && a.nt <= NB / 16 ? a.nt : NB / 16;
+    if (nt < NB / 16) {
+        // inverse rows of the padding part: X[i][j] = (i == j), stored at W[j][i + 1] (columns beyond the factored block)
+        const int r0 = 16 * nt, nr = NB - r0;
+        for (int idx = tid; idx < nr * NB; idx += PD_THREADS) {
+            const int i = r0 + idx / NB, j = idx % NB;
+            if (j <= i) W[j * WLD + i + 1] = (i == j) ? 1.0 : 0.0;
+        }
+    }
     if (a.shift_rel != 0.0) {
         __syncthreads();
-        if (tid < NB) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
+        if (tid < 16 * nt) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
     }
     __syncthreads();
     IPM_STAMP(1);
@@ -457,9 +468,9 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
             }
         }
     };
-    const int nfix = potrf_lds<STAMP>(W, dinv_s, NB / 16, thresh, a.big, stamps,
-                                      [&]() { write_rows(0, 16, true, 0, NB - 16); });
-    write_rows(14, 16, false, NB - 16, NB);           // u = 14, 15 cover rows 112..127
+    const int nfix = potrf_lds<STAMP>(W, dinv_s, nt, thresh, a.big, stamps,
+                                      [&]() { write_rows(0, 16, true, 0, 16 * (nt - 1)); });
+    write_rows(2 * (nt - 1), 16, false, 16 * (nt - 1), NB);   // (8 rows per u) the last factored tile row of the inverse and the padding rows
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
     if (a.signal) {

@@ -166,3 +166,44 @@ def test_prepare_is_host_only(golden_dir):
     assert P2.factor == "dense" and isinstance(P2.A, np.ndarray) and P2.A.shape == (64, 128) and P2.perm is None
     Q = S.prepare(*probs[0])
     assert Q.factor == P0.factor and np.array_equal(Q.perm, P0.perm)         # deterministic
+
+
+def test_bench_compact_line_fits_the_driver_tail():
+    """The driver keeps only a tail of stdout: the last line of bench.py must stay under 4 KB (target 2 KB) whatever the
+    per-LP tables hold.  Built from a committed full record of round 3 (25 KB) and from a synthetic worst case."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(root, "profiles", "r03_final_bench.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 20000
+    full["netlib_all"]["projected_makespan_8gpu_s"] = 1.4512345678
+    full["netlib_all"]["slowest_lp"] = "80BAU3B"
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < 2048, len(line)
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert c["value"] == pytest.approx(full["value"], rel=1e-5)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"]
+    assert c["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c["cpu_baseline"])
+    assert c["netlib_all"]["converged"] == full["netlib_all"]["summary"]["converged"]
+    assert c["netlib_all"]["projected_makespan_8gpu_s"] == pytest.approx(1.45123, rel=1e-4)
+    assert "per_lp" not in c["netlib_all"] and "per_lp" not in c["netlib"]
+    # worst case: very long free-text fields and a thousand LPs
+    full["config"]["workload"] = "w" * 5000
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    full["netlib_all"]["per_lp"] = {"LP%04d" % i: {"status": 0, "it": i} for i in range(1000)}
+    assert len(bench.compact_line(full)) < 2048
+    # the netlib workload's own line
+    nl = dict(full["netlib_all"], steps=73, warmup=1, ms_per_step=1.0, higher_is_better=True, scaling="strong",
+              vs_baseline=None, dtype="f64", data="netlib fixtures", config={"workload": "Netlib all"})
+    c2 = json.loads(bench.compact_line(nl))
+    assert c2["summary"]["converged"] == 35 and len(json.dumps(c2)) < 2048

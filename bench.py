@@ -106,7 +106,7 @@ def compact_line(out):
     Netlib legs -- nothing per LP and no prose.  Everything else goes to the detail record (`emit`)."""
     c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                     "vs_baseline", "dtype", "data"))
-    c["config"] = {"workload": _short(out.get("config", {}).get("workload", ""), 200)}
+    c["config"] = {"workload": _short(out.get("config", {}).get("workload", ""), 260)}
     rf = out.get("roofline") or {}
     c["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
                                "flops_per_launch", "avg_launch_ms"))
@@ -135,8 +135,8 @@ def compact_line(out):
         c[key] = e
     # the netlib workload's own line (bench.py --workload netlib) carries these at top level
     if "summary" in out:
-        c["summary"] = _pick(out["summary"], ("n", "converged", "max_iter", "nan", "total_iterations", "timeouts_recovered",
-                                              "serial_launches"))
+        c["summary"] = _pick(out["summary"], ("n", "converged", "max_iter", "nan", "invalid", "errors", "total_iterations",
+                                              "timeouts_recovered", "serial_launches"))
         c.update(_pick(out, ("wall_seconds", "projected_makespan_8gpu_s", "slowest_lp")))
     if "detail" in out:
         c["detail"] = out["detail"]

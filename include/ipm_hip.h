@@ -256,6 +256,12 @@ int ipm_debug_get_stamps(ipm_handle* h, long long* out);
 int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, unsigned char* items, int32_t capacity, int32_t* count,
                           int32_t* tile_items, double sim_us[2]);
 int ipm_get_phase_ms(ipm_handle* h, double out[4]);
+/* Diagnostic (environment IPM_FF_TRACE_ITEMS=1 at ipm_create; IPM_ERR_STATE otherwise): time line of the LAST fused formation +
+ * factorization launch on the device-wide 100 MHz clock.  *count = words of the trace: 4 per work item {drawn, inputs ready,
+ * done, worker} followed by 12 per 128-row block {potrf_diag: start, inputs ready, done, -; critical panel: same; critical
+ * update: same}; out (capacity words) receives it when large enough; items (8 bytes each, may be NULL) the work list,
+ * *nitems its length.  tools/ff_trace.py turns it into per-step stall tables. */
+int ipm_debug_ff_trace(ipm_handle* h, long long* out, int64_t capacity, int64_t* count, unsigned char* items, int32_t* nitems);
 
 #ifdef __cplusplus
 }

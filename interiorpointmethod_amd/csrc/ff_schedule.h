@@ -48,7 +48,7 @@ struct FFItem {
         struct { unsigned short s0, s1; } f;              // F: stage range [s0, s1) of the K loop (BK = 32 stages)
     };
 };
-enum { FF_F = 0, FF_T = 1, FF_D = 2 };     // FF_D(i): max diag(B) over the rows of block i (chain-in-kernel launches only)
+enum { FF_F = 0, FF_T = 1 };
 enum { FF_INIT = 1, FF_ADD_BASE = 2, FF_PANEL = 4, FF_SIG_DIAG0 = 8 };
 constexpr int FF_BATCH = 4;            // columns of L per deferred batch (K = 512)
 constexpr int FF_WINDOW = 2;           // chain look-ahead: columns within this many steps are served at once
@@ -81,8 +81,6 @@ struct FFModel {                       // durations in microseconds (MI355X, one
                                        // four staggered chunks (profiles/r03_ff_timeline_iter.txt).  Measured, worker launch in ms for
                                        // (q_first, q_second) = (4,4) / (8,4) / (16,8) / (16,16): 3.99 / 3.91 / 4.25 / 4.22 -- an even
                                        // earlier start only brings the read-modify-write passes of the updates forward
-    int chain_in_kernel = 0;           // 1: the chain is workgroup 0 of the launch (no launch boundaries; FF_D items head the list)
-    double d_item = 140.0;             // one FF_D item
     double potrf = 38.0, crit_panel = 8.0, crit_update = 6.0, boundary = 3.0;
     int f_stages = 128;                // stages per F chunk (set by the caller: ceil(K / 16 / Q))
     int nstages = 512;                 // K / 16 of the formation
@@ -198,8 +196,6 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     }
     size_t fnext = 0;
     std::multiset<double> events;                       // future times at which the state changes
-    double d_ready = 0.0;                                // max diag(B) known (FF_D items, chain-in-kernel launches)
-    int d_next = M.chain_in_kernel ? 0 : nblk;
     // ---- chain state machine
     int ck = 0, cphase = 0;                             // step, 0: potrf pending, 1: crit panel pending, 2: crit update pending
     double chain_free = 0.0, diag_ready = INF, panel_end = 0.0;
@@ -208,7 +204,7 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
         for (;;) {
             if (ck >= nblk) return;
             if (cphase == 0) {
-                if (ck == 0) { diag_ready = tile_done_time(0, 0); if (diag_ready != INF) diag_ready = std::max(diag_ready, d_ready); }
+                if (ck == 0) diag_ready = tile_done_time(0, 0);
                 if (diag_ready == INF) return;
                 potrf_start[(size_t)ck] = std::max(chain_free + M.boundary, diag_ready);
                 if (trace) fprintf(stderr, "[ff] step %2d potrf start %7.1f (chain free %7.1f, diag ready %7.1f)\n", ck, potrf_start[(size_t)ck], chain_free, diag_ready);
@@ -248,14 +244,6 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     while (!free_at.empty() && remaining > 0) {
         const Ev ev = free_at.top(); free_at.pop();
         const double t = ev.first;
-        if (d_next < nblk) {                            // the scale of the pivot guard first: one item per row block
-            FFItem it{}; it.type = FF_D; it.i = (unsigned char)d_next++;
-            out.items.push_back(it);
-            d_ready = std::max(d_ready, t + M.d_item);
-            events.insert(t + M.d_item);
-            free_at.push(Ev(t + M.d_item, ev.second));
-            continue;
-        }
         advance_chain();
         for (int r = 0; r < nblk; ++r) while (rf[(size_t)r] < r && rowfin[(size_t)r][(size_t)rf[(size_t)r]] <= t) ++rf[(size_t)r];
         int kc = 0;                                     // chain position: diagonal blocks whose factorization has begun

@@ -37,11 +37,7 @@ namespace ipm {
 constexpr int FF_THREADS = 512;
 constexpr int FF_BK = 32, FF_LDT = FF_BK + 2;
 constexpr int FF_OP = 128 * FF_LDT;                    // doubles of one operand tile of one stage
-constexpr int FF_WLD = 130;                            // leading dimension of the chain role's diagonal-block workspace (= WLD of potrf_f64.h)
-constexpr int FF_CHAIN_STG = 128 * 18;                 // chain role: one 128 x 16 slice of the panel tile (rows padded to 18)
-constexpr int FF_LDS_WORKER = 4 * FF_OP;               // workers: P, Q x two buffers = 139,264 B
-constexpr int FF_LDS_CHAIN = 128 * FF_WLD + 128 + FF_CHAIN_STG;   // chain: W + 1 / diag(L) + slice = 152,576 B
-constexpr int FF_LDS_DOUBLES = FF_LDS_CHAIN > FF_LDS_WORKER ? FF_LDS_CHAIN : FF_LDS_WORKER;   // one workgroup per CU either way
+constexpr int FF_LDS_DOUBLES = 4 * FF_OP;              // P, Q x two buffers = 139,264 B: exactly one workgroup per CU
 
 struct FFArgs {
     const double* A; int64_t lda;      // [mp][lda] row-major, zero padded
@@ -49,19 +45,7 @@ struct FFArgs {
     double* B; int64_t ldb;            // [mp][ldb]: tiles, then L in place
     const double* invD;                // [nblk][128*128] inv(L_kk), written by potrf_diag
     double* slab;                      // [ntile][Q][128*128] formation partials
-    const FFItem* items; int nitems;   // the whole list in simulated order (claim == 0: one ticket counter, blocking waits)
-    // claim == 1 (IPM_FF_CLAIM=1, not the default: measured slower): formation chunks and update items are drawn SEPARATELY -- a worker first looks for an update item
-    // that is READY among the first unclaimed ones of the T list (non-blocking checks of the item's hand-off words, the 64
-    // lanes of one wave look at 64 items at once), claims it, and only otherwise takes the next formation chunk: nobody waits
-    // while there is formation work, whatever the simulation got wrong about the timing.  With the formation exhausted the
-    // workers wait for the head items of the T list as before (bounded spins).
-    int claim;
-    int wt;                            // 1: hand-off data stored write-through (sc1), no release; 0: plain stores + one agent-scope release
-    const FFItem* fitems; int nf;      // FF_F / FF_D items, in order
-    const FFItem* titems; int nt;      // FF_T items, in priority order
-    unsigned* fticket;                 // next formation item
-    unsigned* thead;                   // every T item before this index is claimed
-    unsigned* claimed;                 // [nt]
+    const FFItem* items; int nitems;   // the whole list in simulated order: one ticket counter, blocking waits
     unsigned* ticket;                  // [1] next item
     unsigned* fcount;                  // [ntile] formation chunks complete
     unsigned* tprog;                   // [ntile] T items complete (sequence number)
@@ -72,19 +56,11 @@ struct FFArgs {
     unsigned* dbg;                     // [8] diagnostic (first wait that gave up), may be null
     unsigned dbg_words;                // hand-off words to snapshot on that occasion (0: none)
     long long* prof;                   // diagnostic (may be null): [workgroups][16] cycles per phase (s_memtime), see FF_PROF
-    long long* cprof;                  // diagnostic (may be null): chain role, [nblk][4] s_memtime at: inputs of P ready, P done, D done, potrf done
+    long long* trace;                  // diagnostic (may be null, IPM_FF_TRACE_ITEMS=1): [nitems][4] wall_clock64 at {drawn, inputs ready, done} + the worker
     const int* done;
     int nblk, Q, nstages, fstages;     // Q = slab capacity per tile; nstages = K / 16 of the formation (BK = 16 stages of the pair engine)
     int m;                             // true rows: padding rows get a unit diagonal
-    // chain role (workgroup 0 of the launch when chain_in_kernel != 0): the pivot chain without kernel launches
-    int chain_in_kernel;
-    const int* tile_items;             // [ntile] T items per tile (what the chain waits for on its tiles)
     const int* tile_q;                 // [ntile] formation chunks (slabs in use) of the tile, <= Q
-    unsigned long long* maxbits;       // max diag(B) over the true rows as the bit pattern of a non-negative double (FF_D items)
-    unsigned* dcount;                  // FF_D items complete
-    double* maxdiag_out;               // Scalars::maxdiag (for the record)
-    double eps, big, shift_rel;        // pivot guard / Tikhonov shift, as PotrfDiag
-    int* fixed;                        // guarded pivots (accumulates)
 };
 
 // dbg (optional, 8 words, zeroed per launch): the FIRST wait of the launch that gave up records {1, item, kind, target, seen}
@@ -364,213 +340,32 @@ __device__ __forceinline__ void ff_gemm_pair(const double* __restrict__ P0, cons
     __syncthreads();
 }
 
-// Hand-off of a tile / slab to workgroups on other CUs and XCDs.  The data is stored WRITE-THROUGH (sc1 stores: they leave
-// the XCD's L2 at once), every storing wave drains its stores, the workgroup meets, and the caller's lane 0 then bumps the
-// counters; consumers poll, take ONE agent-scope acquire and read with plain loads (cdna guide G16, the write-through form).
-// The plain-store + release-fence form is not used on purpose: the release (buffer_wbl2) writes back EVERY dirty line of the
-// XCD's L2, i.e. the 128-256 KB tiles that the ~30 other workers of the XCD have just stored as well -- measured: each
-// additional formation chunk cost 160-260 us with it (Q = 8 / 16 against Q = 4), and the chain's own kernels, which do
-// release, took 22-25 us instead of 7-10.
-__device__ __forceinline__ void ff_store_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ff_publish_begin(bool release = false) {
+// Hand-off of a tile / slab to workgroups on other CUs and XCDs: plain stores, every storing wave drains its stores, the
+// workgroup meets, ONE lane releases at agent scope (L2 write-back) and the caller's lane 0 then bumps the counters;
+// consumers poll, take one agent-scope acquire and read with plain loads.  (Measured and dropped in round 3: write-through
+// sc1 stores without the release -- 8-byte write-through stores from the MFMA layout cost more than the one fence.)
+__device__ __forceinline__ void ff_publish_begin() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (release && threadIdx.x == 0) {          // plain-store form (FFArgs::wt == 0): one lane releases for the workgroup
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// CHAIN role: the pivot chain of the blocked Cholesky inside the persistent launch (workgroup 0), instead of three kernel
-// launches per step on a second stream.  Per step k:
-//   P   L(k,k-1) = tile(k,k-1) inv(L(k-1,k-1))^T   -- the inverse is still in the LDS workspace W of the previous potrf
-//                 (upper triangle, shifted one column: potrf_f64.h), the tile streams through a 128 x 16 slice buffer;
-//                 the result goes to memory (write-through) and into W, which the inverse no longer needs;
-//   D   tile(k,k) -= L(k,k-1) L(k,k-1)^T           -- both operands from W, the tile from memory (the workers applied the
-//                 columns before k-1), the result back into W: it never travels through memory;
-//   potrf_lds(W)  -- the 128 x 128 guarded Cholesky of potrf_f64.h -- then L(k,k) and inv(L(k,k)) to memory, potrfdone[k].
-// No launch boundaries, no dispatcher between the steps, and no CU has to be kept free for it: every other workgroup of the
-// launch is a worker.  Hand-offs with the workers are the same counters the multi-launch chain used.
-__device__ __attribute__((noinline)) void ff_chain_role(const FFArgs& g, double* lds) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, fk = lane >> 4;
-    const int er = wm * 64 + fk, ec = wn * 32 + fr;          // this lane's elements of a tile: row er + 16 i + 4 q, col ec + 16 j
-    double* W = lds;                                         // [128][FF_WLD]
-    double* dinv_s = lds + 128 * FF_WLD;                     // [128]
-    double* stg = dinv_s + 128;                              // [128][18]
-    double thresh = 0.0, maxdiag = 0.0;
-#define FF_CSTAMP(slot) do { if (g.cprof && tid == 0) g.cprof[(size_t)k * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (int k = 0; k < g.nblk; ++k) {
-        double* Bkk = g.B + (int64_t)k * 128 * (g.ldb + 1);
-        if (k == 0) {
-            if (tid == 0) {
-                ff_wait_ge(g.dcount, (unsigned)g.nblk, g.timeout, g.dbg, 9000u, 8, g.dbg_words);
-                ff_wait_ge(g.dready, 10u, g.timeout, g.dbg, 9000u, 9, g.dbg_words);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            FF_CSTAMP(0);
-            maxdiag = __longlong_as_double((long long)__hip_atomic_load(g.maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            thresh = g.eps * maxdiag;
-            if (tid == 0) *g.maxdiag_out = maxdiag;
-            // tile (0,0): rows complete up to the end of their 16-wide diagonal tile (what potrf_lds reads)
-            f64x2 v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = tid + u * FF_THREADS, i = idx >> 6, c2 = (idx & 63) * 2;
-                v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(Bkk + (int64_t)i * g.ldb + c2) : (f64x2){0.0, 0.0};
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int idx = tid + u * FF_THREADS, i = idx >> 6, c2 = (idx & 63) * 2;
-                if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * FF_WLD + c2]) = v[u];
-            }
-        } else {
-            // ---- P: L(k,k-1) = tile(k,k-1) X^T, X = inv(L(k-1,k-1)): X[c][kk] (kk <= c) sits at W[kk * FF_WLD + c + 1]
-            double* tkk1 = g.B + (int64_t)k * 128 * g.ldb + (int64_t)(k - 1) * 128;
-            if (tid == 0) {
-                ff_wait_ge(g.tprog + ff_tile(k, k - 1), (unsigned)g.tile_items[ff_tile(k, k - 1)], g.timeout, g.dbg, 9000u + k, 6, g.dbg_words);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            FF_CSTAMP(0);
-            f64x4 pl[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pl[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-            // slice staging: thread -> 16-byte chunk sc (of 8) of rows sr and sr + 64
-            const int sc = tid & 7, sr = tid >> 3;
-            f64x2 sv[2];
-            sv[0] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)sr * g.ldb + sc * 2);
-            sv[1] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)(sr + 64) * g.ldb + sc * 2);
-            for (int sl = 0; sl < 8; ++sl) {
-                *reinterpret_cast<f64x2*>(stg + sr * 18 + sc * 2) = sv[0];
-                *reinterpret_cast<f64x2*>(stg + (sr + 64) * 18 + sc * 2) = sv[1];
-                __syncthreads();
-                if (sl + 1 < 8) {
-                    sv[0] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)sr * g.ldb + (sl + 1) * 16 + sc * 2);
-                    sv[1] = *reinterpret_cast<const f64x2*>(tkk1 + (int64_t)(sr + 64) * g.ldb + (sl + 1) * 16 + sc * 2);
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int kidx = sl * 16 + kk * 4 + fk;
-                    double a[4], b[2];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = stg[(wm * 64 + i * 16 + fr) * 18 + kk * 4 + fk];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { const int c = wn * 32 + j * 16 + fr; b[j] = (kidx <= c) ? W[kidx * FF_WLD + c + 1] : 0.0; }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) pl[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], pl[i][j], 0, 0, 0);
-                }
-                __syncthreads();                              // the slice buffer is rewritten next
-            }
-            // L(k,k-1) to memory (write-through) and into W (the inverse is dead: every wave passed the barrier above)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = er + i * 16 + 4 * q, c = ec + j * 16;
-                        ff_store_wt(tkk1 + (int64_t)r * g.ldb + c, pl[i][j][q]);
-                        W[r * FF_WLD + c] = pl[i][j][q];
-                    }
-            ff_publish_begin();
-            FF_CSTAMP(1);
-            if (tid == 0) {
-                __hip_atomic_fetch_add(g.lfinal + k, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // ---- D needs the diagonal tile with every column before k-1 applied
-                ff_wait_ge(g.tprog + ff_tile(k, k), (unsigned)g.tile_items[ff_tile(k, k)], g.timeout, g.dbg, 9000u + k, 7, g.dbg_words);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            f64x4 dd[4][2], tv[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    dd[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) tv[i][j][q] = Bkk[(int64_t)(er + i * 16 + 4 * q) * g.ldb + ec + j * 16];
-                }
-            for (int kk = 0; kk < 32; ++kk) {
-                double a[4], b[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = W[(wm * 64 + i * 16 + fr) * FF_WLD + kk * 4 + fk];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = W[(wn * 32 + j * 16 + fr) * FF_WLD + kk * 4 + fk];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) dd[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], dd[i][j], 0, 0, 0);
-            }
-            __syncthreads();                                  // every read of L(k,k-1) in W is done
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) W[(er + i * 16 + 4 * q) * FF_WLD + ec + j * 16] = tv[i][j][q] - dd[i][j][q];
-        }
-        if (g.shift_rel != 0.0) {
-            __syncthreads();
-            if (tid < 128) W[tid * FF_WLD + tid] += g.shift_rel * maxdiag;
-        }
-        __syncthreads();
-        FF_CSTAMP(2);
-        // ---- the diagonal block itself; L and the first 112 rows of the inverse go out under the assembly of the last inverse row
-        double* inv = const_cast<double*>(g.invD) + (int64_t)k * 128 * 128;
-        auto write_rows = [&](int u0, int u1, bool want_l, int inv_lo, int inv_hi) {
-            for (int u = u0; u < u1; ++u) {
-                const int idx = tid + u * FF_THREADS, i = idx >> 6, j = (idx & 63) * 2;
-                if (j <= i) {
-                    const bool wi = i >= inv_lo && i < inv_hi;
-                    if (j + 1 <= i) {
-                        if (want_l) *reinterpret_cast<f64x2*>(Bkk + (int64_t)i * g.ldb + j) = (f64x2){W[i * FF_WLD + j], W[i * FF_WLD + j + 1]};
-                        if (wi) *reinterpret_cast<f64x2*>(inv + i * 128 + j) = (f64x2){W[j * FF_WLD + i + 1], W[(j + 1) * FF_WLD + i + 1]};
-                    } else {
-                        if (want_l) Bkk[(int64_t)i * g.ldb + j] = W[i * FF_WLD + j];
-                        if (wi) inv[i * 128 + j] = W[j * FF_WLD + i + 1];
-                    }
-                }
-            }
-        };
-        const int nfix = potrf_lds<false>(W, dinv_s, 8, thresh, g.big, nullptr, [&]() { write_rows(0, 16, true, 0, 112); });
-        write_rows(14, 16, false, 112, 128);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (nfix) atomicAdd(g.fixed, nfix);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (plain 16-byte stores above; this XCD's L2 holds little else dirty)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(const_cast<unsigned*>(g.potrfdone) + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        FF_CSTAMP(3);
-    }
-#undef FF_CSTAMP
-}
-
 // phases of the diagnostic cycle profile (IPM_FF_PROF=1; tools/ff_debug.py): wave 0 stamps s_memtime at phase boundaries
 enum { FFP_TICKET = 0, FFP_FGEMM, FFP_FSTORE, FFP_TWAIT, FFP_TGEMM, FFP_TBASE, FFP_PWAIT, FFP_PGEMM, FFP_TSTORE, FFP_NF, FFP_NT, FFP_TOTAL };
-#define FF_PROF(slot) do { if (g.prof && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); g.prof[(size_t)blockIdx.x * 16 + (slot)] += t_ - tprev; tprev = t_; } } while (0)
+#define FF_PROF(slot) do { if (TRACE && g.prof && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); g.prof[(size_t)blockIdx.x * 16 + (slot)] += t_ - tprev; tprev = t_; } } while (0)
+// per-item time line on the device-wide 100 MHz clock (tools/ff_trace.py)
+#define FF_TRACE(slot) do { if (TRACE && g.trace && tid == 0) g.trace[(size_t)n * 4 + (slot)] = (long long)wall_clock64(); } while (0)
 
-// CLAIM / INKER / WT: the three opt-in variants (FFArgs::claim, ::chain_in_kernel, ::wt) are separate instantiations, so that
-// the shipped one carries none of their code: the worker loop sits at the register limit and every extra path costs spills.
-template <bool CLAIM, bool INKER, bool WT>
+// TRACE: the diagnostic instantiation (IPM_FF_PROF / IPM_FF_TRACE_ITEMS) carries the stamps; the shipped one none of their
+// code -- the worker loop sits at the register limit and every extra path costs spills.
+template <bool TRACE>
 __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     if (g.done && *g.done) return;
     __shared__ __attribute__((aligned(16))) double lds[FF_LDS_DOUBLES];
-    __shared__ unsigned ticket_s, f_left_s, head_s;
-    __shared__ unsigned long long mask_s[16];
+    __shared__ unsigned ticket_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -578,118 +373,24 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
     // this lane's 32 elements of a 128 x 128 tile (accumulator layout): row = er + i*16 + 4q, col = ec + j*16
     const int er = wm * 64 + fk, ec = wn * 32 + fr;
 
-    if (INKER && blockIdx.x == 0) { ff_chain_role(g, lds); return; }
-    long long tprev = g.prof ? __builtin_amdgcn_s_memtime() : 0;
+    long long tprev = (TRACE && g.prof) ? __builtin_amdgcn_s_memtime() : 0;
     const long long tstart = tprev;
-    if (threadIdx.x == 0) f_left_s = 1u;                    // formation items may be left
-    __syncthreads();
     for (;;) {
-        constexpr unsigned SEL_EXIT = 0xffffffffu, SEL_T = 0x80000000u;
-        if (!CLAIM) {
-            if (tid == 0) {
-                const unsigned n0 = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ticket_s = n0 < (unsigned)g.nitems ? n0 : SEL_EXIT;
-            }
-        } else if constexpr (CLAIM) {
-            // all 8 waves look at the 512 update items behind the head: the first READY unclaimed one is claimed
-            for (unsigned spins = 0;; ++spins) {
-                if (tid == 0) head_s = __hip_atomic_load(g.thead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                const unsigned h = head_s;                    // ONE head for the whole window (other workgroups move it meanwhile)
-                const unsigned n = h + (unsigned)tid;
-                bool open = false, cand = false;
-                if (n < (unsigned)g.nt) {
-                    // every load of a lane is issued before the first is used: two memory latencies per look, not seven
-                    const unsigned cl = __hip_atomic_load(g.claimed + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const FFItem ti_ = g.titems[n];
-                    const int tl = ff_tile(ti_.i, ti_.c);
-                    const unsigned v_f = __hip_atomic_load(g.fcount + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v_t = __hip_atomic_load(g.tprog + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v_i = __hip_atomic_load(g.lfinal + ti_.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v_c = __hip_atomic_load(g.lfinal + ti_.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v_p = __hip_atomic_load(g.potrfdone + ti_.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    open = cl == 0u;
-                    bool ok = open;
-                    if (ti_.t.flags & FF_ADD_BASE) ok = ok & (v_f >= (unsigned)g.tile_q[tl]);
-                    if (!(ti_.t.flags & FF_INIT)) ok = ok & (v_t >= (unsigned)ti_.t.seq - 1u);
-                    if (ti_.t.j1 > ti_.t.j0) ok = ok & (v_i >= 4u * ti_.t.j1) & (v_c >= 4u * ti_.t.j1);
-                    if (ti_.t.flags & FF_PANEL) ok = ok & (v_p >= 1u);
-                    cand = ok;
-                }
-                const unsigned long long mask = __ballot(cand), openmask = __ballot(open);
-                if (lane == 0) { mask_s[wave] = mask; mask_s[8 + wave] = openmask; }
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned first_open = 0xffffffffu;
-                    for (int w8 = 7; w8 >= 0; --w8) if (mask_s[8 + w8]) first_open = h + 64u * (unsigned)w8 + (unsigned)__builtin_ctzll(mask_s[8 + w8]);
-                    unsigned sel = 0xfffffffeu;                          // "look again"
-                    bool any_ready = false;
-                    // the ready items in list order: the first one nobody else has taken meanwhile
-                    for (int w8 = 0; w8 < 8 && sel == 0xfffffffeu; ++w8) {
-                        unsigned long long mk = mask_s[w8];
-                        while (mk) {
-                            any_ready = true;
-                            const unsigned c_ = h + 64u * (unsigned)w8 + (unsigned)__builtin_ctzll(mk);
-                            if (__hip_atomic_exchange(g.claimed + c_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { sel = SEL_T | c_; break; }
-                            mk &= mk - 1;
-                        }
-                    }
-                    if (any_ready) {
-                        // (every ready item was snatched: look again)
-                    } else {
-                        // the head moves over the claimed prefix of the window
-                        const unsigned nh = first_open != 0xffffffffu ? first_open : min(h + 512u, (unsigned)g.nt);
-                        if (nh > h) __hip_atomic_fetch_max(g.thead, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (f_left_s) {
-                            const unsigned fn = __hip_atomic_fetch_add(g.fticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (fn < (unsigned)g.nf) sel = fn; else f_left_s = 0u;
-                        }
-                        if (sel == 0xfffffffeu && !f_left_s) {
-                            // no formation work left: back to the ORDERED form -- take the first open item whether it is ready or
-                            // not and wait for it inside (one lane polls its hand-off words; hundreds of idle workgroups scanning
-                            // the list would only take memory bandwidth from the workgroups that still compute)
-                            if (first_open == 0xffffffffu) { if (nh >= (unsigned)g.nt) sel = SEL_EXIT; }
-                            else if (__hip_atomic_exchange(g.claimed + first_open, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) sel = SEL_T | first_open;
-                        }
-                    }
-                    ticket_s = sel;
-                }
-                __syncthreads();
-                if (ticket_s != 0xfffffffeu) break;
-            }
+        constexpr unsigned SEL_EXIT = 0xffffffffu;
+        if (tid == 0) {
+            const unsigned n0 = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket_s = n0 < (unsigned)g.nitems ? n0 : SEL_EXIT;
         }
         __syncthreads();
         const unsigned n = ticket_s;
         __syncthreads();                                   // ticket_s is rewritten on the next turn
-        if (n == SEL_EXIT) { if (g.prof && tid == 0) g.prof[(size_t)blockIdx.x * 16 + FFP_TOTAL] = __builtin_amdgcn_s_memtime() - tstart; return; }
-        const FFItem it = !CLAIM ? g.items[n] : ((n & SEL_T) ? g.titems[n & ~SEL_T] : g.fitems[n]);
+        if (n == SEL_EXIT) { if (TRACE && g.prof && tid == 0) g.prof[(size_t)blockIdx.x * 16 + FFP_TOTAL] = __builtin_amdgcn_s_memtime() - tstart; return; }
+        const FFItem it = g.items[n];
         FF_PROF(FFP_TICKET);
+        FF_TRACE(0);
+        if (TRACE && g.trace && tid == 0) g.trace[(size_t)n * 4 + 3] = (long long)blockIdx.x;
         const int ti = it.i, tc = it.c;
         const int tile = ff_tile(ti, tc);
-        if (INKER && it.type == FF_D) {
-            // ---- diag(B) of the true rows of block ti straight from A and d -> running maximum (the pivot guard's scale): one
-            //      wave per row, 16 rows per wave; max of non-negative doubles through their bit patterns (order independent)
-            double mx = 0.0;
-            for (int rr = wave; rr < 128; rr += 8) {
-                const int row = ti * 128 + rr;
-                if (row >= g.m) break;
-                const double* a = g.A + (int64_t)row * g.lda;
-                double sacc = 0.0;
-                for (int kq = lane * 2; kq < g.nstages * FF_PBK; kq += 128) {
-                    const f64x2 va = *reinterpret_cast<const f64x2*>(a + kq);
-                    const f64x2 vd = *reinterpret_cast<const f64x2*>(g.d + kq);
-                    sacc = __builtin_fma(va.x * va.x, vd.x, sacc);
-                    sacc = __builtin_fma(va.y * va.y, vd.y, sacc);
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
-                mx = (sacc > mx) ? sacc : mx;            // NaN never wins
-            }
-            if (lane == 0) atomicMax(g.maxbits, (unsigned long long)__double_as_longlong(mx));
-            ff_publish_begin();
-            if (tid == 0) __hip_atomic_fetch_add(g.dcount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
-        }
         if (it.type == FF_F) {
             // ---- one K-chunk of the formation of the tile PAIR (ti, tc), (ti + 1, tc): raw partial tiles -> slabs (tile, q).
             //      A half above the diagonal (ti < tc) or below the matrix (ti + 1 == nblk) is computed on a stand-in panel and
@@ -717,16 +418,17 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) { if (WT) ff_store_wt(sb + (i * 16 + 4 * q) * 128 + j * 16, pacc[i][j][q]); else sb[(i * 16 + 4 * q) * 128 + j * 16] = pacc[i][j][q]; }
+                            for (int q = 0; q < 4; ++q) sb[(i * 16 + 4 * q) * 128 + j * 16] = pacc[i][j][q];
                 }
             }
-            ff_publish_begin(!WT);
+            ff_publish_begin();
             if (tid == 0) {
                 if (up) __hip_atomic_fetch_add(g.fcount + ff_tile(ti, tc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lo) __hip_atomic_fetch_add(g.fcount + ff_tile(ti + 1, tc), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NF] += 1;
+                if (TRACE && g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NF] += 1;
             }
             FF_PROF(FFP_FSTORE);
+            FF_TRACE(2);
             continue;
         }
 
@@ -750,6 +452,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         }
         __syncthreads();
         FF_PROF(FFP_TWAIT);
+        FF_TRACE(1);
         if (j1 > j0)
             ff_gemm_pipe<false>(g.B + (int64_t)ti * 128 * g.ldb + (int64_t)j0 * 128, g.ldb,
                                 g.B + (int64_t)tc * 128 * g.ldb + (int64_t)j0 * 128, g.ldb, nullptr, (j1 - j0) * (128 / FF_BK), lds, acc);
@@ -823,15 +526,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { if (WT) ff_store_wt(bt + (int64_t)(i * 16 + 4 * q) * g.ldb + j * 16, val[i][j][q]); else bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16] = val[i][j][q]; }
-        ff_publish_begin(!WT);
+                for (int q = 0; q < 4; ++q) bt[(int64_t)(i * 16 + 4 * q) * g.ldb + j * 16] = val[i][j][q];
+        ff_publish_begin();
         if (tid == 0) {
             __hip_atomic_store(g.tprog + tile, (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (flags & FF_PANEL) __hip_atomic_fetch_add(g.lfinal + ti, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (flags & FF_SIG_DIAG0) __hip_atomic_fetch_add(g.dready, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NT] += 1;
+            if (TRACE && g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NT] += 1;
         }
         FF_PROF(FFP_TSTORE);
+        FF_TRACE(2);
     }
 }
 

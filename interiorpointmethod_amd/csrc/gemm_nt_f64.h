@@ -60,6 +60,7 @@ struct GemmNT {
     unsigned wait_count;
     unsigned* timeout;          // set to 1 when the bounded poll gave up (surfaced as an error by the host)
     unsigned* dbg; unsigned dbg_tag;   // diagnostic (may be null): the first poll of a call that ran into its bound records {1, tag, 6, target, seen}
+    long long* trace;                  // diagnostic (may be null): wall_clock64 of workgroup 0 at {start, inputs ready, done}
 };
 
 // bijective XCD-aware remap of the linear workgroup id (blocks b and b+8 share an XCD, so
@@ -93,6 +94,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
         if (g.signal && threadIdx.x == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[0] = (long long)wall_clock64();
     if (g.wait_on) {
         if (threadIdx.x == 0) {
             unsigned spins = 0;
@@ -116,6 +118,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
         }
         __syncthreads();
     }
+    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[1] = (long long)wall_clock64();
 
     __shared__ __attribute__((aligned(16))) double lds[2 * (BM + BN) * LDT];
     double* Ps = lds;                           // [2][BM][LDT]
@@ -279,6 +282,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
             __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[2] = (long long)wall_clock64();
 }
 
 // C tile = beta*C + alpha * (sum of the split_p slabs of that tile, in chunk order); one tail tile per

@@ -159,27 +159,18 @@ struct ipm_handle {
     int ff_min_nblk = 20, ff_max_nblk = 40;
     bool ff_forced = false;
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
-    int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: all CUs but one with
-                                          // the chain in the kernel, 7/8 of the CUs with the chain as launches on a second stream)
-    int ff_chain_in_kernel = 0;           // IPM_FF_CHAIN=kernel: the pivot chain as workgroup 0 of the persistent launch instead of three kernel
-                                          // launches per step on the second stream.  Built, correct, SLOWER: one CU needs 34 + 22 us for the panel solve and
-                                          // the tile update of a step (the launches spread them over 4 + 10 workgroups: 12 + 7 us) and potrf itself runs at
-                                          // 46-58 us beside the workers' memory traffic: 115 us per step against 56 (profiles/r03_ff_chain_in_kernel_prof.txt)
+    int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: 7/8 of the CUs, see ff_build)
     int* d_ff_tile_items = nullptr;       // [tile_items | tile_q]
     int ff_qmax = 16;                     // slab capacity per tile (the first block rows are formed in more, shorter chunks)
     bool ff_built = false, ff_last = false;
     FFSchedule ff_sched;
-    FFItem* d_ff_items = nullptr;         // [all | F and D items | T items]
-    int ff_nf = 0, ff_nt = 0;
-    int ff_claim = 0;                     // IPM_FF_CLAIM=1: update items are drawn when READY (non-blocking look at the first 512 open ones), formation
-                                          // chunks otherwise -- built, correct, slower (4.88 against 3.91 ms: the launch is dependency bound, and a worker
-                                          // already waiting in front of an item picks it up with no latency); default: ONE ticket counter over the simulated
-                                          // order, blocking waits
-    unsigned* d_ff_flags = nullptr;       // ticket[16] | maxdiag ticket[16] | fcount[ntile] | tprog[ntile] | lfinal[nblk] | dready[nblk] | potrfdone[nblk]
+    FFItem* d_ff_items = nullptr;         // the work list in ticket order
+    unsigned* d_ff_flags = nullptr;       // ticket[16] | maxdiag ticket[8] | dbg[8] | fcount[ntile] | tprog[ntile] | lfinal[nblk] | dready[nblk] | potrfdone[nblk]
     size_t ff_flag_words = 0;
     double* ff_slab = nullptr;            // [ntile][Q][128*128]
     double* ff_part = nullptr;            // [256] block maxima of ff_maxdiag_kernel
     hipEvent_t ev_ffjoin = nullptr;
+    long long* ff_trace = nullptr;        // IPM_FF_TRACE_ITEMS=1: [nitems][4] per-item time line + [nblk][12] chain kernels (ipm_debug_ff_trace)
     long long* ff_prof = nullptr;         // IPM_FF_PROF=1: [workers][16] cycle profile of the persistent launch (accumulates)
     const int* fdone = nullptr;           // `done` word the formation / factorization kernels test (null: Scalars::done; the overlapped
                                           // path points it at the per-iteration latch Scalars::done_f)
@@ -574,8 +565,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; h->ff_forced = true; } else h->ff_enabled = atoi(e); }
     if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
-    if (const char* e = getenv("IPM_FF_CLAIM")) h->ff_claim = atoi(e);
-    if (const char* e = getenv("IPM_FF_CHAIN")) h->ff_chain_in_kernel = strcmp(e, "kernel") == 0;
     if (const char* e = getenv("IPM_FF_Q")) h->ff_q = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("IPM_FF_WORKERS")) h->ff_workers = std::max(1, atoi(e));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_ffjoin, hipEventDisableTiming));
@@ -604,17 +593,10 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->ff_prof) {          // diagnostic: where the workers' cycles went (sum over the handle's fused launches)
         (void)hipDeviceSynchronize();
-        std::vector<long long> P(16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk);
+        std::vector<long long> P(16 * ((size_t)h->ff_workers + 1));
         (void)hipMemcpy(P.data(), h->ff_prof, sizeof(long long) * P.size(), hipMemcpyDeviceToHost);
         double tot[16] = {0};
         for (int w = 0; w <= h->ff_workers; ++w) for (int k = 0; k < 16; ++k) tot[k] += (double)P[(size_t)w * 16 + k];
-        if (h->ff_chain_in_kernel) {
-            const long long* C = P.data() + 16 * ((size_t)h->ff_workers + 1);
-            fprintf(stderr, "[ff prof] chain role, last launch, cycles per step (wait for the panel tile | P | wait + D | potrf + write):\n");
-            for (int k = 1; k < h->nblk; ++k)
-                fprintf(stderr, "   step %2d: %7lld | %6lld | %6lld | %6lld\n", k, C[(size_t)k * 4] - C[(size_t)(k - 1) * 4 + 3], C[(size_t)k * 4 + 1] - C[(size_t)k * 4], C[(size_t)k * 4 + 2] - C[(size_t)k * 4 + 1], C[(size_t)k * 4 + 3] - C[(size_t)k * 4 + 2]);
-            fprintf(stderr, "   first block factored %lld cycles after the launch's first stamp; whole chain %lld cycles\n", C[3] - C[0], C[(size_t)(h->nblk - 1) * 4 + 3] - C[0]);
-        }
         static const char* nm[] = {"ticket", "F gemm", "F store+publish", "T wait", "T gemm", "T base+combine", "panel wait", "panel gemm", "T store+publish"};
         double sum = 0; for (int k = 0; k < 9; ++k) sum += tot[k];
         fprintf(stderr, "[ff prof] %d workers, F items %.0f, T items %.0f, cycles per worker in the launches %.3g (sum of phases %.3g)\n", h->ff_workers, tot[FFP_NF], tot[FFP_NT], tot[FFP_TOTAL] / h->ff_workers, sum / h->ff_workers);
@@ -639,7 +621,7 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
     for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->B_own, (void*)h->invD_own, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
-                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof, (void*)h->d_ff_tile_items})
+                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof, (void*)h->ff_trace, (void*)h->d_ff_tile_items})
         dev_free(h->device, h->stream, p);
     free_sparse_factor(h);
     for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
@@ -1480,6 +1462,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         pd.wait_on = nullptr; pd.wait_count = 0; pd.signal = nullptr; pd.timeout = nullptr; pd.dbg = nullptr; pd.dbg_tag = 0;
+        pd.trace = nullptr;
         pd.nt = potrf_panels(h, k);
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
@@ -1653,22 +1636,18 @@ static int ff_build(ipm_handle* h) {
     if (h->ff_workers <= 0) {
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
-        // Chain in the kernel (default): one workgroup per CU on EVERY CU, workgroup 0 runs the pivot chain, the rest work.
-        // Chain as launches on the second stream: one workgroup per CU on all CUs but ONE PER SHADER ENGINE -- 7 of the 8
-        // CUs of each of the 32 engines on MI355X = 224 workers; the 32 CUs left empty host the chain's kernels.  Measured
-        // (2048 x 4100, 16 blocks, tools/ff_debug.py): with 248 / 247 workers a workgroup of a chain kernel can wait forever
-        // (always, resp. usually: the launch then ends through its spin bounds), with 240 / 232 in 1 of 6 / 5 of 8 runs, with
-        // 224 never -- the dispatcher deals workgroups to XCDs and engines round-robin without regard to where the free CUs
-        // are, so EVERY engine needs a free one.  That is what the chain-in-kernel form does away with.
-        h->ff_workers = h->ff_chain_in_kernel ? std::max(1, prop.multiProcessorCount - 1)
-                                              : std::max(8, prop.multiProcessorCount - prop.multiProcessorCount / 8);
+        // One workgroup per CU on all CUs but ONE PER SHADER ENGINE -- 7 of the 8 CUs of each of the 32 engines on MI355X =
+        // 224 workers; the 32 CUs left empty host the chain's kernels.  Measured (2048 x 4100, 16 blocks): with 248 / 247
+        // workers a workgroup of a chain kernel can wait forever (always, resp. usually: the launch then ends through its
+        // spin bounds), with 240 / 232 in 1 of 6 / 5 of 8 runs, with 224 never -- the dispatcher deals workgroups to XCDs
+        // and engines round-robin without regard to where the free CUs are, so EVERY engine needs a free one.
+        h->ff_workers = std::max(8, prop.multiProcessorCount - prop.multiProcessorCount / 8);
     }
     const int nstages = (int)(h->np / FF_PBK);               // BK = 16 stages of the pair engine
     const int Q = std::max(1, std::min(h->ff_q, nstages));
     h->ff_q = Q;
     FFModel M;
     M.f_stages = (nstages + Q - 1) / Q; M.nstages = nstages;
-    if (h->ff_chain_in_kernel) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
     h->ff_qmax = std::max(Q, std::min(16, nstages));
     ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched, h->ff_qmax);
     const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
@@ -1676,7 +1655,6 @@ static int ff_build(ipm_handle* h) {
         std::vector<int> fcnt(ntile, 0), base(ntile, 0), applied(ntile, 0), paneled(ntile, 0);
         for (const FFItem& it : h->ff_sched.items) {
             const size_t t = (size_t)ff_tile(it.i, it.c);
-            if (it.type == FF_D) continue;
             if (it.type == FF_F) {
                 if (it.c <= it.i) fcnt[t]++;
                 if (it.i + 1 < h->nblk) fcnt[(size_t)ff_tile(it.i + 1, it.c)]++;
@@ -1695,24 +1673,23 @@ static int ff_build(ipm_handle* h) {
             }
     }
     const size_t nit = h->ff_sched.items.size();
-    std::vector<FFItem> all(h->ff_sched.items), fl, tl;
-    for (const FFItem& it : h->ff_sched.items) (it.type == FF_T ? tl : fl).push_back(it);
-    h->ff_nf = (int)fl.size(); h->ff_nt = (int)tl.size();
-    all.insert(all.end(), fl.begin(), fl.end());
-    all.insert(all.end(), tl.begin(), tl.end());
-    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * all.size()));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, all.data(), sizeof(FFItem) * all.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));          // (`all` is a local)
+    HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_items, sizeof(FFItem) * nit));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ff_items, h->ff_sched.items.data(), sizeof(FFItem) * nit, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_tile_items, sizeof(int) * 2 * ntile));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_tile_items, h->ff_sched.tile_items.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_ff_tile_items + ntile, h->ff_sched.tile_q.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
-    h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk + (size_t)h->ff_nt;      // ... | claimed[nT]
+    h->ff_flag_words = 32 + 2 * ntile + 3 * (size_t)h->nblk;
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->d_ff_flags, sizeof(unsigned) * 2 * h->ff_flag_words));     // live words + diagnostic snapshot
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_slab, sizeof(double) * ntile * (size_t)h->ff_qmax * 128 * 128));
     HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_part, sizeof(double) * 256));
     if (getenv("IPM_FF_PROF")) {
-        HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_prof, sizeof(long long) * (16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk)));
-        HIP_TRY(h, hipMemsetAsync(h->ff_prof, 0, sizeof(long long) * (16 * ((size_t)h->ff_workers + 1) + 4 * (size_t)h->nblk), h->stream));
+        HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_prof, sizeof(long long) * 16 * ((size_t)h->ff_workers + 1)));
+        HIP_TRY(h, hipMemsetAsync(h->ff_prof, 0, sizeof(long long) * 16 * ((size_t)h->ff_workers + 1), h->stream));
+    }
+    if (getenv("IPM_FF_TRACE_ITEMS")) {
+        const size_t words = 4 * nit + 12 * (size_t)h->nblk;
+        HIP_TRY(h, dev_malloc(h->device, h->stream, (void**)&h->ff_trace, sizeof(long long) * words));
+        HIP_TRY(h, hipMemsetAsync(h->ff_trace, 0, sizeof(long long) * words, h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->ff_built = true;
@@ -1734,47 +1711,34 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
              *potrfdone = dready + nblk;
     unsigned* timeout = h->d_flags + 2 * (size_t)nblk;
     HIP_TRY(h, hipMemsetAsync(F, 0, sizeof(unsigned) * h->ff_flag_words, sw));
-    const bool inker = h->ff_chain_in_kernel != 0;
-    if (!inker) {
-        HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
-        HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
-        // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
-        // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
-        // formation chunks -- the first diagonal tile is not ready before those are done anyway
-        hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
-                           &h->sc->maxdiag, done);
-    }
+    HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
+    HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
+    // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
+    // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
+    // formation chunks -- the first diagonal tile is not ready before those are done anyway
+    hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
+                       &h->sc->maxdiag, done);
     FFArgs a;
     memset(&a, 0, sizeof a);
     a.A = h->A; a.lda = h->np; a.d = h->d; a.B = h->B; a.ldb = h->mp; a.invD = h->invD; a.slab = h->ff_slab;
     a.items = h->d_ff_items; a.nitems = (int)h->ff_sched.items.size();
-    a.claim = h->ff_claim ? 1 : 0;
-    // IPM_FF_WT=1: write-through hand-off stores instead of plain stores + one release per item -- measured slower (8-byte sc1
-    // stores: 4.55 against 4.21 ms in an A/B of one build)
-    { static const int wt = getenv("IPM_FF_WT") ? atoi(getenv("IPM_FF_WT")) : 0; a.wt = wt; }
-    a.fitems = h->d_ff_items + a.nitems; a.nf = h->ff_nf; a.titems = a.fitems + h->ff_nf; a.nt = h->ff_nt;
-    a.fticket = F + 1; a.thead = F + 2; a.claimed = potrfdone + nblk;
     a.ticket = ticket; a.fcount = fcount; a.tprog = tprog; a.lfinal = lfinal; a.dready = dready; a.potrfdone = potrfdone;
     a.timeout = timeout; a.dbg = dbg; a.done = done;
     { static const bool dbg_on = getenv("IPM_FF_DEBUG") != nullptr; a.dbg_words = dbg_on ? (unsigned)h->ff_flag_words : 0u; }
+    a.trace = h->ff_trace;
+    long long* ctrace = h->ff_trace ? h->ff_trace + 4 * h->ff_sched.items.size() : nullptr;
     a.prof = h->ff_prof;
-    a.cprof = h->ff_prof ? h->ff_prof + 16 * ((size_t)h->ff_workers + 1) : nullptr;
-    a.chain_in_kernel = inker ? 1 : 0; a.tile_items = h->d_ff_tile_items; a.tile_q = h->d_ff_tile_items + ntile;
-    a.maxbits = (unsigned long long*)(F + 8); a.dcount = F + 10; a.maxdiag_out = &h->sc->maxdiag;
-    a.eps = h->opt.pivot_guard_eps; a.big = h->opt.pivot_guard_big; a.shift_rel = h->shift_rel; a.fixed = &h->sc->fixed;
+    a.tile_q = h->d_ff_tile_items + ntile;
     a.nblk = nblk; a.Q = h->ff_qmax; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
     {
-        const dim3 grid((unsigned)h->ff_workers + (inker ? 1u : 0u));
-        if (inker) hipLaunchKernelGGL((form_factor_kernel<false, true, false>), grid, dim3(FF_THREADS), 0, sw, a);
-        else if (a.claim) hipLaunchKernelGGL((form_factor_kernel<true, false, false>), grid, dim3(FF_THREADS), 0, sw, a);
-        else if (a.wt) hipLaunchKernelGGL((form_factor_kernel<false, false, true>), grid, dim3(FF_THREADS), 0, sw, a);
-        else hipLaunchKernelGGL((form_factor_kernel<false, false, false>), grid, dim3(FF_THREADS), 0, sw, a);
+        const dim3 grid((unsigned)h->ff_workers);
+        if (a.prof || a.trace) hipLaunchKernelGGL((form_factor_kernel<true>), grid, dim3(FF_THREADS), 0, sw, a);
+        else hipLaunchKernelGGL((form_factor_kernel<false>), grid, dim3(FF_THREADS), 0, sw, a);
     }
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], sw));
     HIP_TRY(h, hipGetLastError());
     h->n_counter_steps = 0; h->n_event_steps = 0; h->last_gs = 1;
-    if (inker) { h->n_counter_steps = nblk; h->ff_last = true; return IPM_OK; }      // the chain is workgroup 0 of that launch
     for (int k = 0; k < nblk; ++k) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
@@ -1782,6 +1746,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         pd.maxdiag = &h->sc->maxdiag; pd.eps = h->opt.pivot_guard_eps; pd.big = h->opt.pivot_guard_big; pd.shift_rel = h->shift_rel;
         pd.fixed = &h->sc->fixed; pd.done = done; pd.stamps = nullptr;
         pd.wait_on = dready + k; pd.wait_count = 10; pd.signal = potrfdone + k; pd.timeout = timeout; pd.dbg = dbg; pd.dbg_tag = (unsigned)k;
+        pd.trace = ctrace ? ctrace + 12 * (size_t)k : nullptr;
         pd.nt = potrf_panels(h, k);
         hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         ++h->n_counter_steps;
@@ -1802,6 +1767,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         tc.wait_on = tprog + ff_tile(k + 1, k); tc.wait_count = (unsigned)h->ff_sched.tile_items[(size_t)ff_tile(k + 1, k)];
         tc.signal = lfinal + (k + 1); tc.timeout = timeout;         // four workgroups, one count each: 4 = one final tile
         tc.dbg = dbg; tc.dbg_tag = 1000u + (unsigned)k;
+        tc.trace = ctrace ? ctrace + 12 * (size_t)k + 4 : nullptr;
         HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));
         GemmNT uc = gemm_defaults();                                // tile (k+1,k+1) -= L(k+1,k) L(k+1,k)^T
         uc.tile_order = nullptr; uc.batch = 1; uc.batch2 = 1;
@@ -1811,6 +1777,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
         uc.wait_on = tprog + ff_tile(k + 1, k + 1); uc.wait_count = (unsigned)h->ff_sched.tile_items[(size_t)ff_tile(k + 1, k + 1)];
         uc.signal = dready + (k + 1); uc.timeout = timeout;         // ten 32 x 32 sub-tiles, one count each
         uc.dbg = dbg; uc.dbg_tag = 2000u + (unsigned)k;
+        uc.trace = ctrace ? ctrace + 12 * (size_t)k + 8 : nullptr;
         HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));
     }
     HIP_TRY(h, hipEventRecord(h->ev_ffjoin, sm));
@@ -1828,12 +1795,26 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     FFModel M;
     M.f_stages = std::max(1, 512 / q); M.nstages = 512;       // K = 8192 (the headline size's formation), BK = 16 stages
     if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) { M.nstages = std::max(q, atoi(e)); M.f_stages = (M.nstages + q - 1) / q; }
-    if (getenv("IPM_FF_CHAIN") && !strcmp(getenv("IPM_FF_CHAIN"), "kernel")) { M.chain_in_kernel = 1; M.boundary = 0.0; M.crit_panel = 10.0; M.crit_update = 9.0; }
     ff_build_schedule(nblk, q, workers, M, S, std::max(q, 16));
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));
     if (tile_items) for (size_t t = 0; t < S.tile_items.size(); ++t) tile_items[t] = S.tile_items[t];
     if (sim_us) { sim_us[0] = S.makespan_us; sim_us[1] = S.form_end_us; }
+    return IPM_OK;
+}
+
+extern "C" int ipm_debug_ff_trace(ipm_handle* h, long long* out, int64_t capacity, int64_t* count, unsigned char* items, int32_t* nitems) {
+    if (!h || !count) return fail(h, IPM_ERR_INVALID_ARG, "ipm_debug_ff_trace: bad arguments");
+    if (!h->ff_trace || !h->ff_built) return fail(h, IPM_ERR_STATE, "no item trace (IPM_FF_TRACE_ITEMS=1 at ipm_create, fused path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nit = h->ff_sched.items.size(), words = 4 * nit + 12 * (size_t)h->nblk;
+    *count = (int64_t)words;
+    if (nitems) *nitems = (int32_t)nit;
+    if (out && capacity >= (int64_t)words) {
+        HIP_TRY(h, hipMemcpyAsync(out, h->ff_trace, sizeof(long long) * words, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (items) memcpy(items, h->ff_sched.items.data(), sizeof(FFItem) * nit);
     return IPM_OK;
 }
 
@@ -2096,7 +2077,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
         const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
         static const bool ff_overlap = !(getenv("IPM_FF_OVERLAP") && atoi(getenv("IPM_FF_OVERLAP")) == 0);
-        if (fused && (!ff_overlap || h->ff_chain_in_kernel)) {
+        if (fused && !ff_overlap) {
             // experiment: no residual-stream work beside the fused launch -- residuals, group inverses after it, in stream order
             if ((rc = enqueue_form_factor(h, ev, -1, -1))) return rc;
             h->fdone = nullptr;

@@ -53,6 +53,7 @@ struct PotrfDiag {
     unsigned* dbg; unsigned dbg_tag;   // diagnostic (may be null): see GemmNT::dbg; kind 7
     int nt;                            // 16-wide panels to factor (1 .. 8): the rows from 16 nt on are PADDING rows (unit diagonal, nothing else):
                                        // L and inv(L) are the identity there, exactly what factoring them gives, without the pivots
+    long long* trace;                  // diagnostic (may be null): wall_clock64 at {start, inputs ready, done}
 };
 
 // sqrt(p) and 1/sqrt(p) from v_rsq_f64 (about 23 good bits) and one Halley step
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.trace && tid == 0) a.trace[0] = (long long)wall_clock64();
     if (a.wait_on) {
         if (tid == 0) {
             unsigned spins = 0;
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     }
     const double thresh = a.eps * (*a.maxdiag);
     long long* stamps = a.stamps;
+    if (a.trace && tid == 0) a.trace[1] = (long long)wall_clock64();
 
     IPM_STAMP(0);
     // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
     if (nt < NB / 16) {
         // inverse rows of the padding part: X[i][j] = (i == j), stored at W[j][i + 1] (columns beyond the factored block)
         const int r0 = 16 * nt, nr = NB - r0;
+        __syncthreads();      // the block load above also stores W[j][j+1..(j|15)] of the padding rows: the fill must come second
         for (int idx = tid; idx < nr * NB; idx += PD_THREADS) {
             const int i = r0 + idx / NB, j = idx % NB;
             if (j <= i) W[j * WLD + i + 1] = (i == j) ? 1.0 : 0.0;
@@ -482,6 +486,7 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
             __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (a.trace && tid == 0) a.trace[2] = (long long)wall_clock64();
 }
 
 // max of the diagonal of an n x n matrix (single workgroup; n <= a few 10^4)

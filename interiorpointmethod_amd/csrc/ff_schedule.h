@@ -16,19 +16,17 @@
 // Why an ordered list and one ticket counter: a worker takes the next item of the list, waits (bounded spin) for what the
 // item needs, runs it.  Everything an item needs is produced by items EARLIER in the list (or by the chain, which itself
 // only needs earlier items), and earlier items are held by workgroups that are running, so the launch cannot deadlock
-// whatever the residency or timing; a bad order only costs waiting.  The order is the start order of a discrete-event
-// simulation of the machine (workers, chain, durations measured on MI355X) under a priority rule:
-//   (0) tiles in the chain's window (their column is at most 2 steps ahead) as soon as anything can be applied to them,
-//   (1) final batches (everything up to the tile's last column is available),
-//   (2) batches of >= FF_BATCH columns for tiles further away (few read-modify-write passes per tile),
-//   (3) the next formation chunk (column-major, so that columns become complete in the order the chain needs them),
-//   (4) anything left once the formation is exhausted.
-// The list is a pure function of (nblk, Q, workers): the arithmetic order of every tile is fixed, results are bitwise
-// reproducible.
+// whatever the residency or timing; a bad order only costs waiting.  The order is the start order of a list scheduling of
+// the item DAG by bottom level on durations calibrated with an item trace of the launch itself (ff_build_schedule below;
+// tools/ff_replay.py replays a list under the same model and reproduces the measured chain to ~1 %).
+// The list is a pure function of (nblk, Q, workers, model): the arithmetic order of every tile is fixed, results are
+// bitwise reproducible.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <math.h>
 
 #include <algorithm>
 #include <limits>
@@ -43,15 +41,13 @@ struct FFItem {
     unsigned char i, c;        // tile
     unsigned char q;           // F: K-chunk (slab index)
     union {
-        struct { unsigned char j0, j1, flags, seq; } t;   // T: column range of L applied; FF_INIT | FF_ADD_BASE | FF_PANEL | FF_SIG_DIAG0;
+        struct { unsigned char j0, j1, flags, seq; } t;   // T: column range of L applied; FF_INIT | FF_ADD_BASE | FF_PANEL | FF_SIG_DIAG;
                                                           //    1-based sequence number among the tile's T items (tprog hand-off)
         struct { unsigned short s0, s1; } f;              // F: stage range [s0, s1) of the K loop (BK = 32 stages)
     };
 };
-enum { FF_F = 0, FF_T = 1 };
-enum { FF_INIT = 1, FF_ADD_BASE = 2, FF_PANEL = 4, FF_SIG_DIAG0 = 8 };
-constexpr int FF_BATCH = 4;            // columns of L per deferred batch (K = 512)
-constexpr int FF_WINDOW = 2;           // chain look-ahead: columns within this many steps are served at once
+enum { FF_F = 0, FF_T = 1, FF_D = 2 };     // FF_D(i): max diag(B) over the rows of block i straight from A and d (chain_mode 1)
+enum { FF_INIT = 1, FF_ADD_BASE = 2, FF_PANEL = 4, FF_SIG_DIAG = 8 };     // SIG_DIAG: the finished diagonal tile is handed to the chain (dready[i] += 10)
 constexpr int FF_MAX_NBLK = 96;
 
 #if defined(__HIPCC__)
@@ -61,273 +57,263 @@ constexpr int FF_MAX_NBLK = 96;
 #endif
 FF_HD inline int ff_tile(int i, int c) { return i * (i + 1) / 2 + c; }
 
-struct FFModel {                       // durations in microseconds (MI355X, one 512-thread workgroup per CU)
-    double stage = 4.4;                // one BK = 32 stage of a 128 x 128 tile (update / panel items; 4.2-4.4 standalone)
-    double pstage = 3.95;              // one BK = 16 stage of a 256 x 128 tile PAIR (formation): 3.91 us standalone; inside the fused
-                                       // launch 9280 cycles at the 2.1 GHz the chip holds there = 4.4 us (in-kernel cycle profile)
-    // The durations below are DELIBERATELY on the optimistic side of what the cycle profile shows (T overhead 10.5 + 3 us,
-    // panel product 19 us, formation stage 4.4 us): the list is drawn in order with blocking waits, and an order that
-    // expects the chain's inputs early puts a worker in front of each of them before it is ready, so that the hand-off
-    // costs no pick-up time.  Measured at 4096 x 8192, 224 workers: 3.91 ms with these values, 4.19-4.26 ms with the
-    // profile's own; drawing ready items without waiting (IPM_FF_CLAIM=1) 4.88 ms -- the launch is bound by the chain's
-    // dependencies, not by the order of the list.
-    double f_overhead = 6.0;           // F chunk: prologue + slab stores + drain
-    double t_overhead = 7.0;           // T item: ticket, wait + acquire, tile load, combine, store + drain
-    double t_base = 2.0;               // reading Q slabs
-    double t_panel = 16.0;             // second product with inv(L_cc) (4 stages + staging through LDS)
-    int batch = 4, window = 2;         // columns per deferred batch; chain look-ahead (FF_BATCH / FF_WINDOW)
-    int q_first = 8, q_second = 4;     // formation chunks per tile for the block rows 0-3 / 4-7 (capped by the slab capacity): the chain
-                                       // cannot start before the first diagonal tile is formed -- at 0.98 ms of a 3.96 ms launch with
-                                       // four staggered chunks (profiles/r03_ff_timeline_iter.txt).  Measured, worker launch in ms for
-                                       // (q_first, q_second) = (4,4) / (8,4) / (16,8) / (16,16): 3.99 / 3.91 / 4.25 / 4.22 -- an even
-                                       // earlier start only brings the read-modify-write passes of the updates forward
-    double potrf = 38.0, crit_panel = 8.0, crit_update = 6.0, boundary = 3.0;
-    int f_stages = 128;                // stages per F chunk (set by the caller: ceil(K / 16 / Q))
+struct FFModel {                       // durations in microseconds, calibrated on an item trace of the launch itself (MI355X, 512-thread
+                                       // workgroups, one per CU; tools/ff_trace.py -> profiles/r04_ff_item_trace_baseline.txt, tools/ff_replay.py)
+    double f_over = 17.9, f_stage = 3.91;      // formation chunk: fixed + per BK = 16 stage of a 256 x 128 tile pair
+    double t_over = 4.1, t_col = 15.8;         // update item: fixed + per 128-column block of L applied
+    double t_rmw = 2.0, t_panel = 21.0;        // reading the tile back (all but its first item); the product with inv(L_cc)
+    double t_base = 13.0;                      // adding ONE formation slab (53 us for four before the register-major slab layout)
+    double d_item = 140.0;                     // one FF_D item (diag(B) of 128 rows straight from A and d)
+    double gap = 0.8, handoff = 1.5;           // end of an item -> next ticket; counter bump -> visible to a spinning consumer
+    // the pivot chain: potrf_diag of one block, and -- chain_mode 0 only -- its two small GEMM launches with the launch gaps
+    double potrf = 36.0, cpanel = 8.0, cupdate = 5.0, g_potrf_panel = 3.5, g_panel_update = 3.5, g_update_potrf = 4.0;
+    double chain_start = 220.0;                // chain_mode 0: ff_maxdiag_kernel in front of the first potrf_diag
+    // chain_mode 0: the chain is THREE LAUNCHES per step on a second stream (potrf_diag, panel solve of tile (k+1,k), update of tile
+    //               (k+1,k+1) by column k) on CUs the worker launch leaves free;
+    // chain_mode 1: the chain is ONE persistent single-workgroup launch that factors the diagonal blocks in order (ff_chain_kernel);
+    //               the panel solve of tile (k+1,k) and every update are work items like any other, and FF_D items head the list.
+    int chain_mode = 0;
+    int batch = 4;                     // columns of L per bulk update item
+    int tail = 2;                      // newest columns of a tile applied one at a time (a batch that ends at column j cannot start before
+                                       // L(.,j) exists, i.e. one pipeline step before the tile's final item is due)
+    double stagger = 0.3;              // formation chunk lengths spread over (1 -+ stagger) of the mean, phase per pair: the workers do not
+                                       // finish their chunks in lockstep
     int nstages = 512;                 // K / 16 of the formation
-    int stagger = 1;                   // spread the chunk lengths of the first band (see ff_build_schedule)
-    int row_weight = 10, col_weight = 40;   // formation order key = row_weight (i - 1) + col_weight c (see ff_build_schedule)
+    int q_last = 0;                    // > 0: chunks per pair for the pairs of the last two block rows (shorter chunks pack the end)
 };
 
 struct FFSchedule {
     std::vector<FFItem> items;
-    std::vector<int> tile_items;       // [ntile] T items per tile (what the chain waits for on its tiles)
-    std::vector<int> tile_q;           // [ntile] formation chunks (slabs) of the tile: more for the tiles the chain needs first
+    std::vector<int> tile_items;       // [ntile] T items per tile (what a consumer of the finished tile waits for)
+    std::vector<int> tile_q;           // [ntile] formation chunks (slabs) of the tile
     double makespan_us = 0.0;          // simulated end of the factorization
     double form_end_us = 0.0;          // simulated end of the last formation chunk
 };
 
-// columns of L the WORKERS apply to tile (i,c): the chain applies column c-1 to its diagonal tile itself
-inline int ff_limit(int i, int c) { return (i == c) ? (c > 0 ? c - 1 : 0) : c; }
-inline bool ff_needs_panel(int i, int c) { return i > c + 1; }
+// columns of L the WORKERS apply to tile (i,c); chain_mode 0: the chain's launches apply column c-1 to the diagonal tile themselves
+inline int ff_limit(int i, int c, int chain_mode = 0) { return (i == c && !chain_mode) ? (c > 0 ? c - 1 : 0) : c; }
+inline bool ff_needs_panel(int i, int c, int chain_mode = 0) { return chain_mode ? i > c : i > c + 1; }
 
-// Q: formation chunks per tile (ordinary tiles); Qmax: slab capacity per tile (>= Q; the first block rows use up to it).
+// The work list = the start order of a LIST SCHEDULING of the item DAG on W workers by bottom level (longest path to the end of the
+// factorization, on the calibrated durations above): a worker that comes free takes the open update item with the highest bottom level
+// whose inputs are complete, or -- when a formation chunk has a higher one, or no update is ready -- the next formation chunk; with
+// the formation exhausted it takes the item that becomes ready first and waits inside it.  Everything an item waits for is produced
+// by items EARLIER in the list or by the chain, which itself only waits for earlier items: no deadlock at any timing.
+// Q: formation chunks per pair; Qmax: slab capacity per tile.
 inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSchedule& out, int Qmax = 0) {
     if (Qmax < Q) Qmax = Q;
     const double INF = std::numeric_limits<double>::infinity();
     const int ntile = nblk * (nblk + 1) / 2;
-    const bool trace = getenv("IPM_FF_TRACE") != nullptr;
     FFModel Mx = M_in;
-    if (const char* e = getenv("IPM_FF_ROW_WEIGHT")) Mx.row_weight = atoi(e);
-    if (const char* e = getenv("IPM_FF_COL_WEIGHT")) Mx.col_weight = atoi(e);
-    if (const char* e = getenv("IPM_FF_STAGGER")) Mx.stagger = atoi(e);
     if (const char* e = getenv("IPM_FF_BATCH")) Mx.batch = std::max(1, atoi(e));
-    if (const char* e = getenv("IPM_FF_WINDOW")) Mx.window = std::max(1, atoi(e));
-    if (const char* e = getenv("IPM_FF_Q_FIRST")) Mx.q_first = std::max(1, atoi(e));
-    if (const char* e = getenv("IPM_FF_Q_SECOND")) Mx.q_second = std::max(1, atoi(e));
+    if (const char* e = getenv("IPM_FF_TAIL")) Mx.tail = std::max(1, atoi(e));
+    if (const char* e = getenv("IPM_FF_STAGGER")) Mx.stagger = std::min(0.9, std::max(0.0, atof(e)));
+    if (const char* e = getenv("IPM_FF_Q_LAST")) Mx.q_last = std::max(0, atoi(e));
     const FFModel& M = Mx;
-    struct Tile {
-        int i, c, limit; bool panel;
-        int f_sched = 0; double f_time = 0.0;          // F chunks scheduled, latest finish
-        int qn = 0;                                    // F chunks of the tile
-        bool base_in = false, paneled = false;
-        int applied = 0, nitems = 0;
-        double ready = 0.0;                            // finish time of the last T item scheduled on the tile
-        bool complete() const { return base_in && applied == limit && (!panel || paneled); }
+    const int mode = M.chain_mode;
+    enum Kind { K_F, K_T, K_D, K_POTRF, K_CPANEL, K_CUPDATE };
+    struct Node {
+        Kind kind; int i = 0, c = 0, q = 0, j0 = 0, j1 = 0, flags = 0, seq = 0, s0 = 0, s1 = 0;
+        double dur = 0.0, bl = 0.0, est = 0.0, fin = 0.0;
+        int npred = 0, left = 0;
+        std::vector<int> succ;
     };
-    std::vector<Tile> T((size_t)ntile);
+    std::vector<Node> nd;
+    nd.reserve((size_t)ntile * 6 + 4 * (size_t)nblk);
+    auto add = [&](Kind k, double dur) { Node x; x.kind = k; x.dur = dur; x.fin = INF; nd.push_back(x); return (int)nd.size() - 1; };
+    auto edge = [&](int a, int b) { nd[(size_t)a].succ.push_back(b); nd[(size_t)b].npred++; };
+    // ---- chain
+    std::vector<int> potrf((size_t)nblk), cpan, cupd;
+    for (int k = 0; k < nblk; ++k) { potrf[(size_t)k] = add(K_POTRF, M.potrf + (mode ? M.handoff : M.g_potrf_panel)); nd.back().i = k; }
+    if (!mode) {
+        cpan.resize((size_t)nblk - 1); cupd.resize((size_t)nblk - 1);
+        for (int k = 0; k + 1 < nblk; ++k) { cpan[(size_t)k] = add(K_CPANEL, M.cpanel + M.g_panel_update); nd.back().i = k; }
+        for (int k = 0; k + 1 < nblk; ++k) { cupd[(size_t)k] = add(K_CUPDATE, M.cupdate + M.g_update_potrf); nd.back().i = k; }
+        for (int k = 0; k + 1 < nblk; ++k) { edge(potrf[(size_t)k], cpan[(size_t)k]); edge(cpan[(size_t)k], cupd[(size_t)k]); edge(cupd[(size_t)k], potrf[(size_t)k + 1]); }
+    }
+    // ---- update items per tile
+    std::vector<std::vector<int>> titems((size_t)ntile);
+    std::vector<int> lprod((size_t)ntile, -1);            // node that makes L(r,c) final (c < r)
     for (int i = 0; i < nblk; ++i)
-        for (int c = 0; c <= i; ++c) { Tile& t = T[(size_t)ff_tile(i, c)]; t.i = i; t.c = c; t.limit = ff_limit(i, c); t.panel = ff_needs_panel(i, c); }
-    // rowfin[r][j]: time tile (r, j) became L (j < r)
-    std::vector<std::vector<double>> rowfin((size_t)nblk);
-    for (int r = 0; r < nblk; ++r) rowfin[(size_t)r].assign((size_t)r + 1, INF);
-    std::vector<int> rf((size_t)nblk, 0);              // leading tiles of row r final at the current time
-    std::vector<double> potrf_done((size_t)nblk, INF), potrf_start((size_t)nblk, INF);
-    // Formation order = the order in which the factorization needs the tiles.  The pivot chain reaches column c at about
-    // t0 + c * step; row i does not have to be current before the chain gets to step i - 1, and its own pipeline (update +
-    // panel solve of tile (i,c), needing L(i,c-1)) runs at about half a chain step per column, entirely BEHIND the chain if
-    // it starts at t0 + (i - 1) * step / 2.  Tile (i,c) is therefore needed around (i - 1) / 2 + c / 2 chain steps: the
-    // demand grows linearly in time like the formation's supply does (half of the tiles have i + c <= nblk - 1), whereas a
-    // column-major order needs 3/4 of all tiles by half time and leaves the chain waiting for the formation.
-    // Inside a band of W / Q consecutive tiles the chunks go q-major, so the W concurrent items are W / Q tiles x Q chunks.
-    std::vector<FFItem> forder;
+        for (int c = 0; c <= i; ++c) {
+            const int lim = ff_limit(i, c, mode);
+            const bool pan = ff_needs_panel(i, c, mode);
+            std::vector<std::pair<int, int>> cuts;
+            const int nb_end = std::max(0, lim - M.tail);
+            int j = 0;
+            while (j + M.batch <= nb_end) { cuts.emplace_back(j, j + M.batch); j += M.batch; }
+            if (j < nb_end) { cuts.emplace_back(j, nb_end); j = nb_end; }
+            while (j < lim) { cuts.emplace_back(j, j + 1); ++j; }
+            if (cuts.empty()) cuts.emplace_back(0, 0);
+            std::vector<int>& ids = titems[(size_t)ff_tile(i, c)];
+            for (size_t s = 0; s < cuts.size(); ++s) {
+                const bool last = s + 1 == cuts.size();
+                const int id = add(K_T, M.t_over + M.t_col * (cuts[s].second - cuts[s].first) + (s ? M.t_rmw : 0.0) + ((last && pan) ? M.t_panel : 0.0) + M.handoff + M.gap);
+                Node& x = nd[(size_t)id];
+                x.i = i; x.c = c; x.j0 = cuts[s].first; x.j1 = cuts[s].second; x.seq = (int)s + 1;
+                x.flags = (s == 0 ? FF_INIT : 0) | ((last && pan) ? FF_PANEL : 0) | ((last && i == c && (mode || i == 0)) ? FF_SIG_DIAG : 0);
+                if (s) edge(ids.back(), id);
+                ids.push_back(id);
+            }
+            if (pan) lprod[(size_t)ff_tile(i, c)] = ids.back();
+        }
+    if (!mode) {
+        for (int k = 0; k + 1 < nblk; ++k) {
+            lprod[(size_t)ff_tile(k + 1, k)] = cpan[(size_t)k];
+            edge(titems[(size_t)ff_tile(k + 1, k)].back(), cpan[(size_t)k]);
+            edge(titems[(size_t)ff_tile(k + 1, k + 1)].back(), cupd[(size_t)k]);
+        }
+        edge(titems[0].back(), potrf[0]);
+    } else {
+        for (int k = 0; k < nblk; ++k) edge(titems[(size_t)ff_tile(k, k)].back(), potrf[(size_t)k]);
+    }
+    for (int t = 0; t < ntile; ++t)
+        for (int id : titems[(size_t)t]) {
+            const int i = nd[(size_t)id].i, c = nd[(size_t)id].c, j1 = nd[(size_t)id].j1;
+            if (j1 > nd[(size_t)id].j0) {
+                edge(lprod[(size_t)ff_tile(i, j1 - 1)], id);
+                if (c != i) edge(lprod[(size_t)ff_tile(c, j1 - 1)], id);
+            }
+            if (nd[(size_t)id].flags & FF_PANEL) edge(potrf[(size_t)c], id);
+        }
+    // ---- which update item of a tile adds the formation slabs: the one before the final item (the formation is then needed as late
+    //      as possible without sitting on the tile's last, urgent step)
+    std::vector<int> base_item((size_t)ntile);
+    for (int t = 0; t < ntile; ++t) { const std::vector<int>& ids = titems[(size_t)t]; base_item[(size_t)t] = ids.size() == 1 ? ids[0] : ids[ids.size() - 2]; }
+    // ---- formation chunks of the tile pairs (2r, c), (2r + 1, c)
+    std::vector<int> fch;
+    out.tile_q.assign((size_t)ntile, 0);
     {
-        // formation items are tile PAIRS (2r, c), (2r + 1, c) (form_factor.h: 256 x 128 blocks); a pair is needed when its
-        // more urgent tile is
-        struct Pair { int key, i, c; };
-        std::vector<Pair> order;
+        int npairs = 0;
         for (int i = 0; i < nblk; i += 2)
             for (int c = 0; c <= std::min(i + 1, nblk - 1); ++c) {
-                int key = 1 << 30;
-                if (c <= i) key = std::min(key, M.row_weight * std::max(i - 1, 0) + M.col_weight * c);
-                if (i + 1 < nblk) key = std::min(key, M.row_weight * i + M.col_weight * c);
-                order.push_back(Pair{key, i, c});
-            }
-        std::stable_sort(order.begin(), order.end(), [&](const Pair& a, const Pair& b) { return a.key != b.key ? a.key < b.key : a.c < b.c; });
-        // Chunks per pair: Q, but more for the block rows the chain needs first (FFModel::q_first / q_second), so that the
-        // first diagonal tiles are complete after ~150 us instead of a whole long chunk.
-        // Chunk boundaries in (BK = 16) stages.  Uniform, except for the first band of ordinary pairs (the items most workers
-        // start with): there the chunk lengths are spread over 0.4 .. 1.6 of the mean, so that the workers do not finish their
-        // formation chunks in lockstep -- with equal chunks all of them are deaf for one whole chunk (hundreds of microseconds)
-        // at the same time, and everything the chain waits for waits with them; staggered, one worker comes free every
-        // microsecond or so.
-        const int ns = M.nstages;
-        auto pair_q = [&](const Pair& p) { const int q = p.i < 4 ? M.q_first : (p.i < 8 ? M.q_second : Q); return std::max(1, std::min(std::min(q, Qmax), ns)); };
-        size_t b0 = 0;
-        bool first_band = true;
-        while (b0 < order.size()) {
-            const int qb = pair_q(order[b0]);
-            const size_t band = (size_t)std::max(1, W / qb);
-            size_t b1 = b0;
-            while (b1 < order.size() && b1 < b0 + band && pair_q(order[b1]) == qb) ++b1;
-            std::vector<std::vector<int>> cut(b1 - b0, std::vector<int>((size_t)qb + 1, 0));
-            const bool stag = qb == Q && first_band && Q > 1 && M.stagger;
-            if (qb == Q) first_band = false;
-            for (size_t t = b0; t < b1; ++t) {
-                std::vector<double> len((size_t)qb, 1.0);
-                if (stag) {
-                    const double phi = (double)(t - b0) / (double)(b1 - b0) / qb;
-                    for (int q = 0; q < qb; ++q) { double u = (double)q / qb + phi; u -= (double)(int)u; len[(size_t)q] = 0.4 + 1.2 * u; }
+                int q = (M.q_last > 0 && i + 2 >= nblk) ? M.q_last : Q;
+                q = std::max(1, std::min(std::min(q, Qmax), M.nstages));
+                const double phi = std::fmod(npairs * 0.381966, 1.0);
+                ++npairs;
+                std::vector<int> cut((size_t)q + 1, 0);
+                double tot = 0.0, acc = 0.0;
+                std::vector<double> len((size_t)q);
+                for (int k = 0; k < q; ++k) { len[(size_t)k] = 1.0 + M.stagger * (2.0 * std::fmod((double)k / q + phi, 1.0) - 1.0); tot += len[(size_t)k]; }
+                for (int k = 0; k < q; ++k) { acc += len[(size_t)k]; cut[(size_t)k + 1] = (int)(M.nstages * acc / tot + 0.5); }
+                cut[(size_t)q] = M.nstages;
+                for (int k = 0; k < q; ++k) {
+                    const int id = add(K_F, M.f_over + M.f_stage * (cut[(size_t)k + 1] - cut[(size_t)k]) + M.gap);
+                    Node& x = nd[(size_t)id];
+                    x.i = i; x.c = c; x.q = k; x.s0 = cut[(size_t)k]; x.s1 = cut[(size_t)k + 1];
+                    fch.push_back(id);
+                    for (int r = i; r <= i + 1; ++r)
+                        if (r >= c && r < nblk) { edge(id, base_item[(size_t)ff_tile(r, c)]); out.tile_q[(size_t)ff_tile(r, c)]++; }
                 }
-                double tot = 0.0; for (double v : len) tot += v;
-                double acc = 0.0;
-                for (int q = 0; q < qb; ++q) { acc += len[(size_t)q]; cut[t - b0][(size_t)q + 1] = (int)(ns * acc / tot + 0.5); }
-                cut[t - b0][(size_t)qb] = ns;
-                if (order[t].c <= order[t].i) T[(size_t)ff_tile(order[t].i, order[t].c)].qn = qb;
-                if (order[t].i + 1 < nblk) T[(size_t)ff_tile(order[t].i + 1, order[t].c)].qn = qb;
             }
-            for (int q = 0; q < qb; ++q)
-                for (size_t t = b0; t < b1; ++t) {
-                    FFItem it{}; it.type = FF_F; it.i = (unsigned char)order[t].i; it.c = (unsigned char)order[t].c; it.q = (unsigned char)q;
-                    it.f.s0 = (unsigned short)cut[t - b0][(size_t)q]; it.f.s1 = (unsigned short)cut[t - b0][(size_t)q + 1];
-                    forder.push_back(it);
-                }
-            b0 = b1;
+    }
+    for (int t = 0; t < ntile; ++t) { Node& x = nd[(size_t)base_item[(size_t)t]]; x.flags |= FF_ADD_BASE; x.dur += M.t_base * out.tile_q[(size_t)t]; }
+    // ---- FF_D items (chain_mode 1): the pivot guard's scale before the first diagonal block is factored
+    std::vector<int> ditems;
+    if (mode) for (int i = 0; i < nblk; ++i) { const int id = add(K_D, M.d_item + M.gap); nd[(size_t)id].i = i; edge(id, potrf[0]); ditems.push_back(id); }
+    // ---- bottom levels
+    const int N = (int)nd.size();
+    {
+        std::vector<int> order, indeg((size_t)N), stack;
+        order.reserve((size_t)N);
+        for (int u = 0; u < N; ++u) { indeg[(size_t)u] = nd[(size_t)u].npred; if (!indeg[(size_t)u]) stack.push_back(u); }
+        while (!stack.empty()) {
+            const int u = stack.back(); stack.pop_back(); order.push_back(u);
+            for (int v : nd[(size_t)u].succ) if (--indeg[(size_t)v] == 0) stack.push_back(v);
+        }
+        if ((int)order.size() != N) { out.items.clear(); return; }          // (cannot happen: the DAG is acyclic by construction)
+        for (size_t k = order.size(); k-- > 0;) {
+            Node& x = nd[(size_t)order[k]];
+            double b = 0.0;
+            for (int v : x.succ) b = std::max(b, nd[(size_t)v].bl);
+            x.bl = x.dur + b;
         }
     }
-    size_t fnext = 0;
-    std::multiset<double> events;                       // future times at which the state changes
-    // ---- chain state machine
-    int ck = 0, cphase = 0;                             // step, 0: potrf pending, 1: crit panel pending, 2: crit update pending
-    double chain_free = 0.0, diag_ready = INF, panel_end = 0.0;
-    auto tile_done_time = [&](int i, int c) -> double { const Tile& t = T[(size_t)ff_tile(i, c)]; return t.complete() ? t.ready : INF; };
-    auto advance_chain = [&]() {
-        for (;;) {
-            if (ck >= nblk) return;
-            if (cphase == 0) {
-                if (ck == 0) diag_ready = tile_done_time(0, 0);
-                if (diag_ready == INF) return;
-                potrf_start[(size_t)ck] = std::max(chain_free + M.boundary, diag_ready);
-                if (trace) fprintf(stderr, "[ff] step %2d potrf start %7.1f (chain free %7.1f, diag ready %7.1f)\n", ck, potrf_start[(size_t)ck], chain_free, diag_ready);
-                potrf_done[(size_t)ck] = potrf_start[(size_t)ck] + M.potrf;
-                events.insert(potrf_start[(size_t)ck]); events.insert(potrf_done[(size_t)ck]);
-                chain_free = potrf_done[(size_t)ck];
-                if (ck + 1 >= nblk) { out.makespan_us = chain_free; ck = nblk; return; }
-                cphase = 1;
-            }
-            if (cphase == 1) {
-                const double tw = tile_done_time(ck + 1, ck);
-                if (tw == INF) return;
-                panel_end = std::max(chain_free + M.boundary, tw) + M.crit_panel;
-                if (trace) fprintf(stderr, "[ff]         panel (%d,%d) input %7.1f chain %7.1f\n", ck + 1, ck, tw, chain_free);
-                rowfin[(size_t)ck + 1][(size_t)ck] = panel_end;
-                events.insert(panel_end);
-                chain_free = panel_end;
-                cphase = 2;
-            }
-            if (cphase == 2) {
-                const double tw = tile_done_time(ck + 1, ck + 1);
-                if (tw == INF) return;
-                if (trace) fprintf(stderr, "[ff]         update (%d,%d) input %7.1f chain %7.1f\n", ck + 1, ck + 1, tw, chain_free);
-                diag_ready = std::max(chain_free + M.boundary, tw) + M.crit_update;
-                events.insert(diag_ready);
-                chain_free = diag_ready;
-                ++ck; cphase = 0;
+    // ---- list scheduling
+    typedef std::pair<double, int> PI;                         // (-bottom level, node): min-heap = highest bottom level first, ties to the lower id
+    std::priority_queue<PI, std::vector<PI>, std::greater<PI>> avail_F;
+    std::set<PI> avail_T;
+    for (int id : fch) avail_F.push(PI(-nd[(size_t)id].bl, id));
+    for (int u = 0; u < N; ++u) nd[(size_t)u].left = nd[(size_t)u].npred;
+    std::vector<int> rel;                                      // release worklist (iterative: the chain releases recursively)
+    auto release = [&](int u0) {
+        rel.clear(); rel.push_back(u0);
+        while (!rel.empty()) {
+            const int u = rel.back(); rel.pop_back();
+            for (int v : nd[(size_t)u].succ) {
+                Node& y = nd[(size_t)v];
+                y.est = std::max(y.est, nd[(size_t)u].fin);
+                if (--y.left == 0) {
+                    if (y.kind == K_T) avail_T.insert(PI(-y.bl, v));
+                    else if (y.kind != K_F && y.kind != K_D) {     // chain nodes run by themselves as soon as their inputs are there
+                        const double st = (y.kind == K_POTRF && y.i == 0 && !mode) ? std::max(y.est, M.chain_start) : y.est;
+                        y.fin = st + y.dur;
+                        rel.push_back(v);
+                    }
+                }
             }
         }
     };
-    typedef std::pair<double, int> Ev;                  // (free time, worker)
+    for (int t = 0; t < ntile; ++t) { const int id = titems[(size_t)t][0]; if (nd[(size_t)id].left == 0) avail_T.insert(PI(-nd[(size_t)id].bl, id)); }
+    typedef std::pair<double, int> Ev;
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> free_at;
     for (int w = 0; w < W; ++w) free_at.push(Ev(0.0, w));
     out.items.clear();
-    size_t remaining = (size_t)ntile;                   // tiles not complete
+    size_t nT = 0, doneT = 0, nextD = 0;
+    for (int t = 0; t < ntile; ++t) nT += titems[(size_t)t].size();
+    std::vector<int> order_out;
     int guard = 0;
-    while (!free_at.empty() && remaining > 0) {
+    while (doneT < nT || !avail_F.empty() || nextD < ditems.size()) {
         const Ev ev = free_at.top(); free_at.pop();
         const double t = ev.first;
-        advance_chain();
-        for (int r = 0; r < nblk; ++r) while (rf[(size_t)r] < r && rowfin[(size_t)r][(size_t)rf[(size_t)r]] <= t) ++rf[(size_t)r];
-        int kc = 0;                                     // chain position: diagonal blocks whose factorization has begun
-        while (kc < nblk && potrf_start[(size_t)kc] <= t) ++kc;
-        // ---- candidates
-        int best = -1, best_class = 99;
-        for (int id = 0; id < ntile; ++id) {
-            const Tile& x = T[(size_t)id];
-            if (x.complete() || x.ready > t) continue;             // done, or an item of the tile is in flight
-            const bool fc = x.f_sched == x.qn && x.f_time <= t;
-            const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
-            const int pend = a - x.applied;
-            const bool can_base = fc && !x.base_in;
-            const bool base_ok = x.base_in || can_base;
-            const bool panel_ready = x.panel && base_ok && a == x.limit && potrf_done[(size_t)x.c] <= t + 8.0;
-            const bool panel_only = panel_ready && x.base_in && pend == 0;
-            if (!(pend > 0 || can_base || panel_only)) continue;
-            // a tile whose LAST column is all that is missing waits for its diagonal block, so that update and panel solve
-            // are one pass over the tile -- while there is formation work to do instead
-            if (x.panel && base_ok && a == x.limit && pend <= 1 && !panel_ready && fnext < forder.size()) continue;
-            int cls;
-            if (x.c <= kc + M.window) cls = 0;
-            else if (base_ok && a == x.limit) cls = 1;
-            else if (pend >= M.batch) cls = 2;
-            else if (can_base && pend == 0 && x.applied == 0 && fnext < forder.size()) continue;   // nothing but the base yet: wait for columns
-            else cls = 4;
-            if (cls == 4 && fnext < forder.size()) continue;       // small deferred batches only once the formation is exhausted
-            if (cls < best_class) { best_class = cls; best = id; }  // ties: lowest tile id = lowest row, then column... see below
-            else if (cls == best_class && best >= 0) {
-                const Tile& y = T[(size_t)best];
-                if (x.c < y.c || (x.c == y.c && x.i < y.i)) best = id;
+        if (nextD < ditems.size()) {
+            const int v = ditems[nextD++];
+            nd[(size_t)v].fin = t + nd[(size_t)v].dur;
+            order_out.push_back(v); release(v);
+            free_at.push(Ev(nd[(size_t)v].fin, ev.second));
+            continue;
+        }
+        int pick = -1;
+        for (const PI& p : avail_T) if (nd[(size_t)p.second].est <= t) { pick = p.second; break; }
+        if (pick >= 0 && !avail_F.empty() && -avail_F.top().first > nd[(size_t)pick].bl) pick = -1;     // a formation chunk is more urgent
+        if (pick < 0 && !avail_F.empty()) {
+            const int v = avail_F.top().second; avail_F.pop();
+            nd[(size_t)v].fin = t + nd[(size_t)v].dur;
+            out.form_end_us = std::max(out.form_end_us, nd[(size_t)v].fin);
+            order_out.push_back(v); release(v);
+            free_at.push(Ev(nd[(size_t)v].fin, ev.second));
+            continue;
+        }
+        if (pick < 0) {
+            if (avail_T.empty()) {                                     // nothing schedulable yet (an item in flight will release the next ones)
+                if (++guard > 64 * W * nblk) break;
+                free_at.push(Ev(t + 5.0, ev.second));
+                continue;
             }
+            double best = INF;                                         // formation exhausted: the item that becomes ready first; wait inside it
+            for (const PI& p : avail_T) if (nd[(size_t)p.second].est < best) { best = nd[(size_t)p.second].est; pick = p.second; }
         }
-        if (best < 0 && fnext < forder.size()) {
-            // ---- a formation chunk
-            const FFItem it = forder[fnext++];
-            const double fin = t + M.f_overhead + M.pstage * (it.f.s1 - it.f.s0);
-            if (it.c <= it.i) { Tile& x = T[(size_t)ff_tile(it.i, it.c)]; x.f_sched++; x.f_time = std::max(x.f_time, fin); }
-            if (it.i + 1 < nblk) { Tile& x = T[(size_t)ff_tile(it.i + 1, it.c)]; x.f_sched++; x.f_time = std::max(x.f_time, fin); }
-            out.form_end_us = std::max(out.form_end_us, fin);
-            events.insert(fin);
-            out.items.push_back(it);
-            free_at.push(Ev(fin, ev.second));
-            continue;
-        }
-        if (best < 0) {
-            // nothing to do right now: sleep until the state changes (at run time: the next ticket's wait)
-            auto nx = events.upper_bound(t);
-            if (nx == events.end()) { if (++guard > 4 * W) break; continue; }       // this worker retires
-            free_at.push(Ev(*nx, ev.second));
-            continue;
-        }
-        // ---- a T item on tile `best`
-        Tile& x = T[(size_t)best];
-        const bool fc = x.f_sched == x.qn && x.f_time <= t;
-        const int a = std::min(std::min(rf[(size_t)x.i], rf[(size_t)x.c]), x.limit);
-        FFItem it{};
-        it.type = FF_T; it.i = (unsigned char)x.i; it.c = (unsigned char)x.c;
-        it.t.j0 = (unsigned char)x.applied; it.t.j1 = (unsigned char)a;
-        if (x.nitems == 0) it.t.flags |= FF_INIT;
-        if (fc && !x.base_in) it.t.flags |= FF_ADD_BASE;
-        const bool base_after = x.base_in || (it.t.flags & FF_ADD_BASE);
-        double dur = M.t_overhead + M.stage * 4.0 * (a - x.applied) + ((it.t.flags & FF_ADD_BASE) ? M.t_base : 0.0);
-        double fin = t + dur;
-        if (x.panel && base_after && a == x.limit && potrf_done[(size_t)x.c] <= t + dur + 8.0) {
-            it.t.flags |= FF_PANEL;
-            fin = std::max(fin, potrf_done[(size_t)x.c]) + M.t_panel;
-        }
-        if (x.i == 0 && x.c == 0) it.t.flags |= FF_SIG_DIAG0;
-        x.applied = a; x.base_in = base_after; x.nitems++; x.ready = fin;
-        it.t.seq = (unsigned char)x.nitems;
-        if (it.t.flags & FF_PANEL) { x.paneled = true; rowfin[(size_t)x.i][(size_t)x.c] = fin; }
-        if (x.complete()) --remaining;
-        if (trace && getenv("IPM_FF_TRACE")[0] == '2')
-            fprintf(stderr, "[ff] t %7.1f T(%d,%d)[%d,%d) flags %d cls %d -> %7.1f\n", t, x.i, x.c, it.t.j0, it.t.j1, it.t.flags, best_class, fin);
-        events.insert(fin);
-        out.items.push_back(it);
-        free_at.push(Ev(fin, ev.second));
+        Node& x = nd[(size_t)pick];
+        avail_T.erase(PI(-x.bl, pick));
+        x.fin = std::max(t, x.est) + x.dur;
+        order_out.push_back(pick); ++doneT;
+        release(pick);
+        free_at.push(Ev(x.fin, ev.second));
     }
-    advance_chain();
+    // ---- encode
     out.tile_items.assign((size_t)ntile, 0);
-    out.tile_q.assign((size_t)ntile, 0);
-    for (int id = 0; id < ntile; ++id) { out.tile_items[(size_t)id] = T[(size_t)id].nitems; out.tile_q[(size_t)id] = T[(size_t)id].qn; }
-    if (out.makespan_us == 0.0) out.makespan_us = chain_free;
+    for (int t = 0; t < ntile; ++t) out.tile_items[(size_t)t] = (int)titems[(size_t)t].size();
+    out.makespan_us = 0.0;
+    for (int v : order_out) {
+        const Node& x = nd[(size_t)v];
+        FFItem it{};
+        it.i = (unsigned char)x.i; it.c = (unsigned char)x.c;
+        if (x.kind == K_F) { it.type = FF_F; it.q = (unsigned char)x.q; it.f.s0 = (unsigned short)x.s0; it.f.s1 = (unsigned short)x.s1; }
+        else if (x.kind == K_D) { it.type = FF_D; }
+        else { it.type = FF_T; it.t.j0 = (unsigned char)x.j0; it.t.j1 = (unsigned char)x.j1; it.t.flags = (unsigned char)x.flags; it.t.seq = (unsigned char)x.seq; }
+        out.items.push_back(it);
+    }
+    for (int k = 0; k < nblk; ++k) out.makespan_us = std::max(out.makespan_us, nd[(size_t)potrf[(size_t)k]].fin);
 }
 
 }  // namespace ipm

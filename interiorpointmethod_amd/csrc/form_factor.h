@@ -58,7 +58,7 @@ struct FFArgs {
     long long* prof;                   // diagnostic (may be null): [workgroups][16] cycles per phase (s_memtime), see FF_PROF
     long long* trace;                  // diagnostic (may be null, IPM_FF_TRACE_ITEMS=1): [nitems][4] wall_clock64 at {drawn, inputs ready, done} + the worker
     const int* done;
-    int nblk, Q, nstages, fstages;     // Q = slab capacity per tile; nstages = K / 16 of the formation (BK = 16 stages of the pair engine)
+    int nblk, Q, nstages;              // Q = slab capacity per tile; nstages = K / 16 of the formation (BK = 16 stages of the pair engine)
     int m;                             // true rows: padding rows get a unit diagonal
     const int* tile_q;                 // [ntile] formation chunks (slabs in use) of the tile, <= Q
 };
@@ -411,14 +411,19 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
                 const int pm = wave >> 1, pn = wave & 1;              // the pair engine's wave grid: 4 (M) x 2 (N)
                 const int half = pm >> 1;                             // 0: upper tile, 1: lower tile
                 if (half == 0 ? up : lo) {
+                    // slab layout = REGISTER-MAJOR: [wave row 2][wave column pair 2][i 4][j 4][q pair 2][lane 64][2] -- every store (and
+                    // every load of the update item that adds the slabs) is one contiguous 1 KB per wave instruction.  The update
+                    // engine's wave (wm, wn) holds columns wn * 32 + j * 16: the same lanes as this engine's wave (wm, wn >> 1), j' =
+                    // (wn & 1) * 2 + j
                     const int tl = ff_tile(ti + half, tc);
-                    double* sb = g.slab + ((size_t)tl * g.Q + it.q) * (128 * 128) + ((pm & 1) * 64 + fk) * 128 + pn * 64 + fr;
+                    double* sb = g.slab + ((size_t)tl * g.Q + it.q) * (128 * 128) + (size_t)((pm & 1) * 2 + pn) * 4096 + lane * 2;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) sb[(i * 16 + 4 * q) * 128 + j * 16] = pacc[i][j][q];
+                            for (int hq = 0; hq < 2; ++hq)
+                                *reinterpret_cast<f64x2*>(sb + ((i * 4 + j) * 2 + hq) * 128) = (f64x2){pacc[i][j][2 * hq], pacc[i][j][2 * hq + 1]};
                 }
             }
             ff_publish_begin();
@@ -475,13 +480,16 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         if (flags & FF_ADD_BASE) {
             const int qn = g.tile_q[tile];
             for (int c = 0; c < qn; ++c) {
-                const double* sb = g.slab + ((size_t)tile * g.Q + c) * (128 * 128) + er * 128 + ec;
+                const double* sb = g.slab + ((size_t)tile * g.Q + c) * (128 * 128) + (size_t)(wm * 2 + (wn >> 1)) * 4096 + lane * 2;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) val[i][j][q] += sb[(i * 16 + 4 * q) * 128 + j * 16];
+                        for (int hq = 0; hq < 2; ++hq) {
+                            const f64x2 v = *reinterpret_cast<const f64x2*>(sb + ((i * 4 + (wn & 1) * 2 + j) * 2 + hq) * 128);
+                            val[i][j][2 * hq] += v.x; val[i][j][2 * hq + 1] += v.y;
+                        }
             }
         }
 #pragma unroll
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         if (tid == 0) {
             __hip_atomic_store(g.tprog + tile, (unsigned)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (flags & FF_PANEL) __hip_atomic_fetch_add(g.lfinal + ti, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (flags & FF_SIG_DIAG0) __hip_atomic_fetch_add(g.dready, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (flags & FF_SIG_DIAG) __hip_atomic_fetch_add(g.dready + ti, 10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (TRACE && g.prof) g.prof[(size_t)blockIdx.x * 16 + FFP_NT] += 1;
         }
         FF_PROF(FFP_TSTORE);

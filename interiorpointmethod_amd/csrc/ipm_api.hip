@@ -158,6 +158,7 @@ struct ipm_handle {
     // default), and only while n <= 3 m.  IPM_FF_MAX_NBLK / IPM_FUSED_FACTOR=force|0 override.
     int ff_min_nblk = 20, ff_max_nblk = 40;
     bool ff_forced = false;
+    int ff_chain_mode = 0;                // FFModel::chain_mode (IPM_FF_CHAIN_MODE): 0 = the pivot chain as three launches per step, 1 = one persistent chain launch
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
     int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: 7/8 of the CUs, see ff_build)
     int* d_ff_tile_items = nullptr;       // [tile_items | tile_q]
@@ -565,6 +566,7 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; h->ff_forced = true; } else h->ff_enabled = atoi(e); }
     if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
+    if (const char* e = getenv("IPM_FF_CHAIN_MODE")) h->ff_chain_mode = atoi(e) != 0;
     if (const char* e = getenv("IPM_FF_Q")) h->ff_q = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("IPM_FF_WORKERS")) h->ff_workers = std::max(1, atoi(e));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_ffjoin, hipEventDisableTiming));
@@ -1647,14 +1649,17 @@ static int ff_build(ipm_handle* h) {
     const int Q = std::max(1, std::min(h->ff_q, nstages));
     h->ff_q = Q;
     FFModel M;
-    M.f_stages = (nstages + Q - 1) / Q; M.nstages = nstages;
-    h->ff_qmax = std::max(Q, std::min(16, nstages));
-    ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched, h->ff_qmax);
+    M.nstages = nstages; M.chain_mode = h->ff_chain_mode;
+    ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched, std::max(Q, std::min(16, nstages)));
+    h->ff_qmax = 1;                                           // slab capacity per tile = the most chunks any tile is formed in
+    for (int q_ : h->ff_sched.tile_q) h->ff_qmax = std::max(h->ff_qmax, q_);
+    if (nstages > 65535) return fail(h, IPM_ERR_INVALID_ARG, "fused factor: %d formation stages exceed the 16-bit stage range of a work item", nstages);
     const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
     {   // every tile complete?  (an incomplete list would be an internal error of the scheduler, never a reason to hang a GPU)
         std::vector<int> fcnt(ntile, 0), base(ntile, 0), applied(ntile, 0), paneled(ntile, 0);
         for (const FFItem& it : h->ff_sched.items) {
             const size_t t = (size_t)ff_tile(it.i, it.c);
+            if (it.type == FF_D) continue;
             if (it.type == FF_F) {
                 if (it.c <= it.i) fcnt[t]++;
                 if (it.i + 1 < h->nblk) fcnt[(size_t)ff_tile(it.i + 1, it.c)]++;
@@ -1668,7 +1673,7 @@ static int ff_build(ipm_handle* h) {
         for (int i = 0; i < h->nblk; ++i)
             for (int c = 0; c <= i; ++c) {
                 const size_t t = (size_t)ff_tile(i, c);
-                if (fcnt[t] != h->ff_sched.tile_q[t] || base[t] != 1 || applied[t] != ff_limit(i, c) || paneled[t] != (ff_needs_panel(i, c) ? 1 : 0))
+                if (fcnt[t] != h->ff_sched.tile_q[t] || base[t] != 1 || applied[t] != ff_limit(i, c, h->ff_chain_mode) || paneled[t] != (ff_needs_panel(i, c, h->ff_chain_mode) ? 1 : 0))
                     return fail(h, IPM_ERR_INVALID_ARG, "fused factor: internal error (tile %d,%d incomplete in the work list)", i, c);
             }
     }
@@ -1729,7 +1734,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     long long* ctrace = h->ff_trace ? h->ff_trace + 4 * h->ff_sched.items.size() : nullptr;
     a.prof = h->ff_prof;
     a.tile_q = h->d_ff_tile_items + ntile;
-    a.nblk = nblk; a.Q = h->ff_qmax; a.nstages = (int)(h->np / FF_PBK); a.fstages = (a.nstages + h->ff_q - 1) / h->ff_q; a.m = (int)h->m;
+    a.nblk = nblk; a.Q = h->ff_qmax; a.nstages = (int)(h->np / FF_PBK); a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
     {
         const dim3 grid((unsigned)h->ff_workers);
@@ -1793,8 +1798,9 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     static_assert(sizeof(FFItem) == 8, "work item layout");
     FFSchedule S;
     FFModel M;
-    M.f_stages = std::max(1, 512 / q); M.nstages = 512;       // K = 8192 (the headline size's formation), BK = 16 stages
-    if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) { M.nstages = std::max(q, atoi(e)); M.f_stages = (M.nstages + q - 1) / q; }
+    M.nstages = 512;                                          // K = 8192 (the headline size's formation), BK = 16 stages
+    if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) M.nstages = std::max(q, atoi(e));
+    if (const char* e = getenv("IPM_FF_CHAIN_MODE")) M.chain_mode = atoi(e) != 0;
     ff_build_schedule(nblk, q, workers, M, S, std::max(q, 16));
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));

@@ -68,10 +68,12 @@ struct FFModel {                       // durations in microseconds, calibrated 
     // the pivot chain: potrf_diag of one block, and -- chain_mode 0 only -- its two small GEMM launches with the launch gaps
     double potrf = 36.0, cpanel = 8.0, cupdate = 5.0, g_potrf_panel = 3.5, g_panel_update = 3.5, g_update_potrf = 4.0;
     double chain_start = 220.0;                // chain_mode 0: ff_maxdiag_kernel in front of the first potrf_diag
-    // chain_mode 0: the chain is THREE LAUNCHES per step on a second stream (potrf_diag, panel solve of tile (k+1,k), update of tile
-    //               (k+1,k+1) by column k) on CUs the worker launch leaves free;
-    // chain_mode 1: the chain is ONE persistent single-workgroup launch that factors the diagonal blocks in order (ff_chain_kernel);
-    //               the panel solve of tile (k+1,k) and every update are work items like any other, and FF_D items head the list.
+    // The chain = per step k: potrf_diag of block k, the panel solve of tile (k+1,k), the update of tile (k+1,k+1) by column k.
+    // chain_mode 0: THREE LAUNCHES per step on a second stream, on CUs the worker launch leaves free (one per shader engine), with
+    //               ff_maxdiag_kernel in front;
+    // chain_mode 1: TWO PERSISTENT launches enqueued before the workers (ff_chain_kernel: one workgroup, the diagonal blocks;
+    //               ff_crit_kernel: four workgroups, the two small products of every step in 32-row strips) -- no launch gaps, and
+    //               every other CU works; FF_D items (max diag(B), the pivot guard's scale) head the list.
     int chain_mode = 0;
     int batch = 4;                     // columns of L per bulk update item
     int tail = 2;                      // newest columns of a tile applied one at a time (a batch that ends at column j cannot start before
@@ -90,9 +92,9 @@ struct FFSchedule {
     double form_end_us = 0.0;          // simulated end of the last formation chunk
 };
 
-// columns of L the WORKERS apply to tile (i,c); chain_mode 0: the chain's launches apply column c-1 to the diagonal tile themselves
-inline int ff_limit(int i, int c, int chain_mode = 0) { return (i == c && !chain_mode) ? (c > 0 ? c - 1 : 0) : c; }
-inline bool ff_needs_panel(int i, int c, int chain_mode = 0) { return chain_mode ? i > c : i > c + 1; }
+// columns of L the WORKERS apply to tile (i,c): the chain applies column c-1 to its diagonal tile itself
+inline int ff_limit(int i, int c) { return (i == c) ? (c > 0 ? c - 1 : 0) : c; }
+inline bool ff_needs_panel(int i, int c) { return i > c + 1; }
 
 // The work list = the start order of a LIST SCHEDULING of the item DAG on W workers by bottom level (longest path to the end of the
 // factorization, on the calibrated durations above): a worker that comes free takes the open update item with the highest bottom level
@@ -124,20 +126,19 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     auto edge = [&](int a, int b) { nd[(size_t)a].succ.push_back(b); nd[(size_t)b].npred++; };
     // ---- chain
     std::vector<int> potrf((size_t)nblk), cpan, cupd;
-    for (int k = 0; k < nblk; ++k) { potrf[(size_t)k] = add(K_POTRF, M.potrf + (mode ? M.handoff : M.g_potrf_panel)); nd.back().i = k; }
-    if (!mode) {
-        cpan.resize((size_t)nblk - 1); cupd.resize((size_t)nblk - 1);
-        for (int k = 0; k + 1 < nblk; ++k) { cpan[(size_t)k] = add(K_CPANEL, M.cpanel + M.g_panel_update); nd.back().i = k; }
-        for (int k = 0; k + 1 < nblk; ++k) { cupd[(size_t)k] = add(K_CUPDATE, M.cupdate + M.g_update_potrf); nd.back().i = k; }
-        for (int k = 0; k + 1 < nblk; ++k) { edge(potrf[(size_t)k], cpan[(size_t)k]); edge(cpan[(size_t)k], cupd[(size_t)k]); edge(cupd[(size_t)k], potrf[(size_t)k + 1]); }
-    }
+    const double g1 = mode ? M.handoff : M.g_potrf_panel, g2 = mode ? M.handoff : M.g_panel_update, g3 = mode ? M.handoff : M.g_update_potrf;
+    for (int k = 0; k < nblk; ++k) { potrf[(size_t)k] = add(K_POTRF, M.potrf + g1); nd.back().i = k; }
+    cpan.resize((size_t)nblk - 1); cupd.resize((size_t)nblk - 1);
+    for (int k = 0; k + 1 < nblk; ++k) { cpan[(size_t)k] = add(K_CPANEL, M.cpanel + g2); nd.back().i = k; }
+    for (int k = 0; k + 1 < nblk; ++k) { cupd[(size_t)k] = add(K_CUPDATE, M.cupdate + g3); nd.back().i = k; }
+    for (int k = 0; k + 1 < nblk; ++k) { edge(potrf[(size_t)k], cpan[(size_t)k]); edge(cpan[(size_t)k], cupd[(size_t)k]); edge(cupd[(size_t)k], potrf[(size_t)k + 1]); }
     // ---- update items per tile
     std::vector<std::vector<int>> titems((size_t)ntile);
     std::vector<int> lprod((size_t)ntile, -1);            // node that makes L(r,c) final (c < r)
     for (int i = 0; i < nblk; ++i)
         for (int c = 0; c <= i; ++c) {
-            const int lim = ff_limit(i, c, mode);
-            const bool pan = ff_needs_panel(i, c, mode);
+            const int lim = ff_limit(i, c);
+            const bool pan = ff_needs_panel(i, c);
             std::vector<std::pair<int, int>> cuts;
             const int nb_end = std::max(0, lim - M.tail);
             int j = 0;
@@ -151,22 +152,18 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
                 const int id = add(K_T, M.t_over + M.t_col * (cuts[s].second - cuts[s].first) + (s ? M.t_rmw : 0.0) + ((last && pan) ? M.t_panel : 0.0) + M.handoff + M.gap);
                 Node& x = nd[(size_t)id];
                 x.i = i; x.c = c; x.j0 = cuts[s].first; x.j1 = cuts[s].second; x.seq = (int)s + 1;
-                x.flags = (s == 0 ? FF_INIT : 0) | ((last && pan) ? FF_PANEL : 0) | ((last && i == c && (mode || i == 0)) ? FF_SIG_DIAG : 0);
+                x.flags = (s == 0 ? FF_INIT : 0) | ((last && pan) ? FF_PANEL : 0) | ((last && i == 0 && c == 0) ? FF_SIG_DIAG : 0);
                 if (s) edge(ids.back(), id);
                 ids.push_back(id);
             }
             if (pan) lprod[(size_t)ff_tile(i, c)] = ids.back();
         }
-    if (!mode) {
-        for (int k = 0; k + 1 < nblk; ++k) {
-            lprod[(size_t)ff_tile(k + 1, k)] = cpan[(size_t)k];
-            edge(titems[(size_t)ff_tile(k + 1, k)].back(), cpan[(size_t)k]);
-            edge(titems[(size_t)ff_tile(k + 1, k + 1)].back(), cupd[(size_t)k]);
-        }
-        edge(titems[0].back(), potrf[0]);
-    } else {
-        for (int k = 0; k < nblk; ++k) edge(titems[(size_t)ff_tile(k, k)].back(), potrf[(size_t)k]);
+    for (int k = 0; k + 1 < nblk; ++k) {
+        lprod[(size_t)ff_tile(k + 1, k)] = cpan[(size_t)k];
+        edge(titems[(size_t)ff_tile(k + 1, k)].back(), cpan[(size_t)k]);
+        edge(titems[(size_t)ff_tile(k + 1, k + 1)].back(), cupd[(size_t)k]);
     }
+    edge(titems[0].back(), potrf[0]);
     for (int t = 0; t < ntile; ++t)
         for (int id : titems[(size_t)t]) {
             const int i = nd[(size_t)id].i, c = nd[(size_t)id].c, j1 = nd[(size_t)id].j1;

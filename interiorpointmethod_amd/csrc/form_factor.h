@@ -61,6 +61,8 @@ struct FFArgs {
     int nblk, Q, nstages;              // Q = slab capacity per tile; nstages = K / 16 of the formation (BK = 16 stages of the pair engine)
     int m;                             // true rows: padding rows get a unit diagonal
     const int* tile_q;                 // [ntile] formation chunks (slabs in use) of the tile, <= Q
+    unsigned long long* maxbits;       // FF_D items: max diag(B) over the true rows as the bit pattern of a non-negative double
+    unsigned* dcount;                  // FF_D items complete
 };
 
 // dbg (optional, 8 words, zeroed per launch): the FIRST wait of the launch that gave up records {1, item, kind, target, seen}
@@ -353,6 +355,110 @@ __device__ __forceinline__ void ff_publish_begin() {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The PIVOT CHAIN as a ROLE of the persistent launch (FFModel::chain_mode 1): the first workgroup to arrive factors the diagonal
+// blocks in order, each as soon as its tile has been handed over (dready[k]), and publishes L_kk / inv(L_kk) (potrfdone[k]).  No
+// launch boundaries on the chain and no CUs kept free for chain launches: ONE launch of as many workgroups as the chip has CUs,
+// dealt evenly by the dispatcher whatever its rotation (separate persistent launches are not: a workgroup whose turn falls on a
+// shader engine that persistent workgroups fill never starts -- measured: intermittent spin-bound time-outs), and the roles are
+// claimed by workgroups that are running.
+struct FFChain {
+    double* B; int64_t ldb; double* invD;
+    const unsigned long long* maxbits; const unsigned* dcount; double* maxdiag_out;
+    const unsigned* dready; unsigned* potrfdone;
+    unsigned* timeout; unsigned* dbg; long long* trace;      // trace: [nblk][12] (slots 0..2 of each block used)
+    double eps, big, shift_rel;
+    int* fixed; const int* done;
+    int nblk, m;
+};
+
+__device__ __forceinline__ void ff_chain_role(const FFChain& c, double* lds) {
+    static_assert(NB * WLD + NB + 2 <= FF_LDS_DOUBLES, "chain role LDS");
+    double* W = lds;                                         // [NB][WLD]
+    double* dinv_s = lds + NB * WLD;                         // [NB]
+    double* maxdiag_p = dinv_s + NB;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        ff_wait_ge(c.dcount, (unsigned)c.nblk, c.timeout, c.dbg, 9000u, 8, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const double mx = __longlong_as_double((long long)__hip_atomic_load(c.maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        *maxdiag_p = mx;
+        *c.maxdiag_out = mx;
+    }
+    __syncthreads();
+    for (int k = 0; k < c.nblk; ++k) {
+        PotrfDiag a;
+        a.Bkk = c.B + (int64_t)k * NB * (c.ldb + 1); a.ld = c.ldb;
+        a.inv = c.invD + (int64_t)k * NB * NB;
+        a.maxdiag = maxdiag_p; a.eps = c.eps; a.big = c.big; a.shift_rel = c.shift_rel;
+        a.fixed = c.fixed; a.done = nullptr; a.stamps = nullptr;
+        a.wait_on = c.dready + k; a.wait_count = 4u; a.signal = c.potrfdone + k; a.timeout = c.timeout; a.dbg = c.dbg; a.dbg_tag = (unsigned)k;
+        a.trace = c.trace ? c.trace + 12 * (size_t)k : nullptr;
+        const int real = c.m - k * NB;                       // 16-wide panels that hold rows of the LP (potrf_panels of the host)
+        a.nt = (c.shift_rel != 0.0 || real >= NB) ? NB / 16 : (real + 15) / 16 < 1 ? 1 : (real + 15) / 16;
+        potrf_diag_body<false>(a, W, dinv_s);
+        __syncthreads();
+    }
+}
+
+// The two small products of every chain step as the role of the next FOUR workgroups to arrive (chain_mode 1), each owning a 32-row
+// strip: L(k+1,k) = tile inv(L_kk)^T in place (a workgroup owns whole rows: BN = N = 128), then tile (k+1,k+1) -= L(k+1,k)
+// L(k+1,k)^T (strip x all rows of L(k+1,k); the part above the diagonal is computed too and never read).  The products are
+// gemm_nt_body<32,128,32,1,8> -- the kernels the launch-per-step chain uses -- with the hand-offs of the fused launch around
+// them: lfinal[k+1] += 1 per strip (4 = the tile is final L), dready[k+1] += 1 per strip (potrf waits for 4).
+struct FFCrit {
+    double* B; int64_t ldb; const double* invD;
+    const unsigned* tprog; const int* tile_items;           // [ntile] T items per tile: the workers' part of a tile is complete
+    const unsigned* potrfdone; unsigned* lfinal; unsigned* dready;
+    unsigned* timeout; unsigned* dbg; long long* trace;
+    const int* done;
+    int nblk;
+};
+constexpr int FF_CRIT_WGS = 4;
+
+__device__ __forceinline__ void ff_crit_role(const FFCrit& c, const int strip, double* lds) {
+    static_assert(2 * (32 + 128) * (32 + 2) <= FF_LDS_DOUBLES, "critical role LDS");
+    const int tid = threadIdx.x;
+    GemmNT g;
+    g.w = nullptr; g.M = 128; g.N = 128; g.K = 128; g.lower = 0; g.unit_diag_from = -1; g.done = nullptr;
+    g.n_direct = FF_CRIT_WGS; g.split_p = 1; g.chunk_stages = 128 / 32; g.slab = nullptr; g.tile_offset = 0; g.tile_order = nullptr;
+    g.sP = g.sQ = g.sC = 0; g.batch = 1; g.sP2 = g.sQ2 = g.sC2 = 0; g.batch2 = 1;
+    g.wait_on = nullptr; g.wait_count = 0; g.timeout = nullptr; g.dbg = nullptr; g.dbg_tag = 0; g.trace = nullptr;
+    for (int k = 0; k + 1 < c.nblk; ++k) {
+        double* panel = c.B + (int64_t)(k + 1) * 128 * c.ldb + (int64_t)k * 128;
+        long long* tr = (c.trace && strip == 0 && tid == 0) ? c.trace + 12 * (size_t)k : nullptr;
+        if (tr) tr[4] = (long long)wall_clock64();
+        if (tid == 0) {
+            const int t = ff_tile(k + 1, k);
+            ff_wait_ge(c.tprog + t, (unsigned)c.tile_items[t], c.timeout, c.dbg, 1000u + (unsigned)k, 6, 0);
+            ff_wait_ge(c.potrfdone + k, 1u, c.timeout, c.dbg, 1000u + (unsigned)k, 6, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tr) tr[5] = (long long)wall_clock64();
+        g.P = panel; g.ldp = c.ldb; g.Q = c.invD + (int64_t)k * 128 * 128; g.ldq = 128;
+        g.C = panel; g.ldc = c.ldb; g.alpha = 1.0; g.beta = 0.0; g.signal = c.lfinal + (k + 1);
+        gemm_nt_body<32, 128, 32, 1, 8, false>(g, strip, 0, 0, lds);
+        if (tr) { tr[6] = (long long)wall_clock64(); tr[8] = tr[6]; }
+        if (tid == 0) {
+            const int t = ff_tile(k + 1, k + 1);
+            ff_wait_ge(c.lfinal + (k + 1), 4u * (unsigned)(k + 1), c.timeout, c.dbg, 2000u + (unsigned)k, 6, 0);
+            ff_wait_ge(c.tprog + t, (unsigned)c.tile_items[t], c.timeout, c.dbg, 2000u + (unsigned)k, 6, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tr) tr[9] = (long long)wall_clock64();
+        g.P = panel; g.ldp = c.ldb; g.Q = panel; g.ldq = c.ldb;
+        g.C = c.B + (int64_t)(k + 1) * 128 * (c.ldb + 1); g.ldc = c.ldb; g.alpha = -1.0; g.beta = 1.0; g.signal = c.dready + (k + 1);
+        gemm_nt_body<32, 128, 32, 1, 8, false>(g, strip, 0, 0, lds);
+        if (tr) tr[10] = (long long)wall_clock64();
+        __syncthreads();
+    }
+}
+
 // phases of the diagnostic cycle profile (IPM_FF_PROF=1; tools/ff_debug.py): wave 0 stamps s_memtime at phase boundaries
 enum { FFP_TICKET = 0, FFP_FGEMM, FFP_FSTORE, FFP_TWAIT, FFP_TGEMM, FFP_TBASE, FFP_PWAIT, FFP_PGEMM, FFP_TSTORE, FFP_NF, FFP_NT, FFP_TOTAL };
 #define FF_PROF(slot) do { if (TRACE && g.prof && tid == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); g.prof[(size_t)blockIdx.x * 16 + (slot)] += t_ - tprev; tprev = t_; } } while (0)
@@ -361,11 +467,22 @@ enum { FFP_TICKET = 0, FFP_FGEMM, FFP_FSTORE, FFP_TWAIT, FFP_TGEMM, FFP_TBASE, F
 
 // TRACE: the diagnostic instantiation (IPM_FF_PROF / IPM_FF_TRACE_ITEMS) carries the stamps; the shipped one none of their
 // code -- the worker loop sits at the register limit and every extra path costs spills.
-template <bool TRACE>
-__global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
-    if (g.done && *g.done) return;
+// Everything the persistent launch of chain_mode 1 needs: the workers' arguments and those of the two chain roles.
+struct FFRoles { FFChain chain; FFCrit crit; unsigned* role; };
+
+template <bool TRACE, bool ROLES>
+__device__ __forceinline__ void form_factor_body(const FFArgs& g, const FFRoles* r) {
     __shared__ __attribute__((aligned(16))) double lds[FF_LDS_DOUBLES];
     __shared__ unsigned ticket_s;
+    if (ROLES) {
+        // roles by ARRIVAL: 0 = the pivot chain, 1 .. 4 = the strips of the critical products, everybody else works
+        if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(r->role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned role = ticket_s;
+        __syncthreads();
+        if (role == 0u) { ff_chain_role(r->chain, lds); return; }
+        if (role <= (unsigned)FF_CRIT_WGS) { ff_crit_role(r->crit, (int)role - 1, lds); return; }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -391,6 +508,31 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         if (TRACE && g.trace && tid == 0) g.trace[(size_t)n * 4 + 3] = (long long)blockIdx.x;
         const int ti = it.i, tc = it.c;
         const int tile = ff_tile(ti, tc);
+        if (it.type == FF_D) {
+            // ---- diag(B) of the true rows of block ti straight from A and d -> running maximum (the pivot guard's scale): one
+            //      wave per row, 16 rows per wave; max of non-negative doubles through their bit patterns (order independent)
+            double mx = 0.0;
+            for (int rr = wave; rr < 128; rr += 8) {
+                const int row = ti * 128 + rr;
+                if (row >= g.m) break;
+                const double* a = g.A + (int64_t)row * g.lda;
+                double sacc = 0.0;
+                for (int kq = lane * 2; kq < g.nstages * FF_PBK; kq += 128) {
+                    const f64x2 va = *reinterpret_cast<const f64x2*>(a + kq);
+                    const f64x2 vd = *reinterpret_cast<const f64x2*>(g.d + kq);
+                    sacc = __builtin_fma(va.x * va.x, vd.x, sacc);
+                    sacc = __builtin_fma(va.y * va.y, vd.y, sacc);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+                mx = (sacc > mx) ? sacc : mx;            // NaN never wins
+            }
+            if (lane == 0) atomicMax(g.maxbits, (unsigned long long)__double_as_longlong(mx));
+            ff_publish_begin();
+            if (tid == 0) __hip_atomic_fetch_add(g.dcount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            FF_TRACE(2);
+            continue;
+        }
         if (it.type == FF_F) {
             // ---- one K-chunk of the formation of the tile PAIR (ti, tc), (ti + 1, tc): raw partial tiles -> slabs (tile, q).
             //      A half above the diagonal (ti < tc) or below the matrix (ti + 1 == nblk) is computed on a stand-in panel and
@@ -544,6 +686,29 @@ __global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
         }
         FF_PROF(FFP_TSTORE);
         FF_TRACE(2);
+    }
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(FF_THREADS, 2) void form_factor_kernel(FFArgs g) {
+    if (g.done && *g.done) return;
+    form_factor_body<TRACE, false>(g, nullptr);
+}
+// chain_mode 1: one launch of as many workgroups as the device has CUs; the chain and the critical products are roles
+template <bool TRACE>
+__global__ __launch_bounds__(FF_THREADS, 2) void form_factor_roles_kernel(FFArgs g, FFRoles r) {
+    if (g.done && *g.done) return;
+    form_factor_body<TRACE, true>(g, &r);
+}
+
+// One wave that waits (bounded) until *flag >= value: the gate in front of the kernels of ANOTHER stream that may only run once
+// the persistent launch has reached a step (chain_mode 1: stream events cannot mark a point inside a launch).  It becomes
+// resident when a CU has room -- at the latest when the first workers leave -- and holds 64 threads while it waits.
+__global__ __launch_bounds__(64) void ff_gate_kernel(const unsigned* flag, unsigned value, unsigned* timeout, const int* done) {
+    if (done && *done) return;
+    if (threadIdx.x == 0) {
+        ff_wait_ge(flag, value, timeout);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 

@@ -74,9 +74,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// One workgroup's share of the contraction (tile picked from bx; by, bz = batch indices); lds: 2 (BM + BN)(BK + 2) doubles.
+// The body of gemm_nt_f64_kernel, and of the persistent critical-step launch of the fused factorization (ff_crit_kernel).
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SCALE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2)   // two workgroups per CU
-void gemm_nt_f64_kernel(GemmNT g) {
+__device__ __forceinline__ void gemm_nt_body(const GemmNT& g, const int bx, const int by, const int bz, double* lds) {
     constexpr bool STORE_EARLY = false;   // measured: writing the next stage before the last k-step is slower (54 vs 60 TFLOP/s)
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -88,39 +89,6 @@ void gemm_nt_f64_kernel(GemmNT g) {
     static_assert((BM * CH) % NT == 0 && (BN * CH) % NT == 0, "tile/threads mismatch");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BK % 4 == 0, "mfma tiling");
 
-    if (g.done && *g.done) {
-        // a skipped producer still signals: the stop test may flip `done` while a factorization is in flight (it runs
-        // on the residual stream), and a consumer that passed its own check must not spin on a counter nobody bumps
-        if (g.signal && threadIdx.x == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[0] = (long long)wall_clock64();
-    if (g.wait_on) {
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
-                __builtin_amdgcn_s_sleep(4);
-                ++spins;
-                // give up (no hang; the host rolls the call back and repeats it with stream events): after ~1 s of
-                // waiting, or at once when an earlier poll of this call already gave up
-                if (spins > (1u << 22) || ((spins & 1023u) == 1u && g.timeout &&
-                                           __hip_atomic_load(g.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (spins > (1u << 22) && g.dbg && __hip_atomic_fetch_add(g.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                        g.dbg[1] = g.dbg_tag; g.dbg[2] = 6u; g.dbg[3] = g.wait_count;
-                        g.dbg[4] = __hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (g.timeout) __hip_atomic_store(g.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
-    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[1] = (long long)wall_clock64();
-
-    __shared__ __attribute__((aligned(16))) double lds[2 * (BM + BN) * LDT];
     double* Ps = lds;                           // [2][BM][LDT]
     double* Qs = lds + 2 * BM * LDT;            // [2][BN][LDT]
 
@@ -135,10 +103,10 @@ void gemm_nt_f64_kernel(GemmNT g) {
     double* slab_out = nullptr;
     {
         int bid;
-        if ((int)blockIdx.x < g.n_direct) {
-            bid = xcd_remap(blockIdx.x, g.n_direct) + g.tile_offset;
+        if (bx < g.n_direct) {
+            bid = xcd_remap(bx, g.n_direct) + g.tile_offset;
         } else {
-            int r = (int)blockIdx.x - g.n_direct;
+            int r = bx - g.n_direct;
             bid = g.tile_offset + g.n_direct + r / g.split_p;
             kbeg = (r % g.split_p) * g.chunk_stages;
             kend = min(kend, kbeg + g.chunk_stages);
@@ -159,8 +127,8 @@ void gemm_nt_f64_kernel(GemmNT g) {
         }
     }
     const int row0 = ti * BM, col0 = tj * BN;
-    const double* Pg = g.P + (int64_t)blockIdx.y * g.sP + (int64_t)blockIdx.z * g.sP2 + (int64_t)row0 * g.ldp;
-    const double* Qg = g.Q + (int64_t)blockIdx.y * g.sQ + (int64_t)blockIdx.z * g.sQ2 + (int64_t)col0 * g.ldq;
+    const double* Pg = g.P + (int64_t)by * g.sP + (int64_t)bz * g.sP2 + (int64_t)row0 * g.ldp;
+    const double* Qg = g.Q + (int64_t)by * g.sQ + (int64_t)bz * g.sQ2 + (int64_t)col0 * g.ldq;
 
     f64x4 acc[MI][NI];
 #pragma unroll
@@ -241,7 +209,7 @@ void gemm_nt_f64_kernel(GemmNT g) {
                 for (int q = 0; q < 4; ++q) sb[(i * 16 + 4 * q) * BN + j * 16] = acc[i][j][q];
         return;
     }
-    double* cbase = g.C + (int64_t)blockIdx.y * g.sC + (int64_t)blockIdx.z * g.sC2 + (int64_t)(row0 + wm * WTM + fk) * g.ldc + col0 + wn * WTN + fr;
+    double* cbase = g.C + (int64_t)by * g.sC + (int64_t)bz * g.sC2 + (int64_t)(row0 + wm * WTM + fk) * g.ldc + col0 + wn * WTN + fr;
     if (g.beta != 0.0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -282,7 +250,46 @@ void gemm_nt_f64_kernel(GemmNT g) {
             __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[2] = (long long)wall_clock64();
+    if (g.trace && threadIdx.x == 0 && bx == 0) g.trace[2] = (long long)wall_clock64();
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SCALE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N) / 2 < 2 ? 1 : 2)   // (<= two waves per SIMD: the register budget of the tiles)
+void gemm_nt_f64_kernel(GemmNT g) {
+    if (g.done && *g.done) {
+        // a skipped producer still signals: the stop test may flip `done` while a factorization is in flight (it runs
+        // on the residual stream), and a consumer that passed its own check must not spin on a counter nobody bumps
+        if (g.signal && threadIdx.x == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[0] = (long long)wall_clock64();
+    if (g.wait_on) {
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
+                __builtin_amdgcn_s_sleep(4);
+                ++spins;
+                // give up (no hang; the host rolls the call back and repeats it with stream events): after ~1 s of
+                // waiting, or at once when an earlier poll of this call already gave up
+                if (spins > (1u << 22) || ((spins & 1023u) == 1u && g.timeout &&
+                                           __hip_atomic_load(g.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    if (spins > (1u << 22) && g.dbg && __hip_atomic_fetch_add(g.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        g.dbg[1] = g.dbg_tag; g.dbg[2] = 6u; g.dbg[3] = g.wait_count;
+                        g.dbg[4] = __hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (g.timeout) __hip_atomic_store(g.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    if (g.trace && threadIdx.x == 0 && blockIdx.x == 0) g.trace[1] = (long long)wall_clock64();
+
+    __shared__ __attribute__((aligned(16))) double lds[2 * (BM + BN) * (BK + 2)];
+    gemm_nt_body<BM, BN, BK, WAVES_M, WAVES_N, SCALE>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
 }
 
 // C tile = beta*C + alpha * (sum of the split_p slabs of that tile, in chunk order); one tail tile per

@@ -53,10 +53,6 @@ struct ipm_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t stream2 = nullptr;            // bulk stream of the Cholesky look-ahead
-    hipStream_t stream_chain = nullptr;       // pivot-chain stream restricted to the 32 CUs of one XCD (IPM_CHAIN_XCD=1): the three
-                                              // chain kernels of a step then hand their 128 KB blocks over through that XCD's L2
-    hipEvent_t ev_join = nullptr;
-    int chain_xcd = 0;
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
     hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr, ev_last = nullptr;
     int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
@@ -158,7 +154,7 @@ struct ipm_handle {
     // default), and only while n <= 3 m.  IPM_FF_MAX_NBLK / IPM_FUSED_FACTOR=force|0 override.
     int ff_min_nblk = 20, ff_max_nblk = 40;
     bool ff_forced = false;
-    int ff_chain_mode = 0;                // FFModel::chain_mode (IPM_FF_CHAIN_MODE): 0 = the pivot chain as three launches per step, 1 = one persistent chain launch
+    int ff_chain_mode = 1;                // FFModel::chain_mode (IPM_FF_CHAIN_MODE): 1 = the pivot chain as roles of the ONE persistent launch (default), 0 = three launches per step on a second stream beside 7/8 of the CUs
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
     int ff_workers = 0;                   // WORKER workgroups of the persistent launch (IPM_FF_WORKERS; default: 7/8 of the CUs, see ff_build)
     int* d_ff_tile_items = nullptr;       // [tile_items | tile_q]
@@ -547,18 +543,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     // onto queues that this handle's chain already occupies (two concurrent solves then serialise: tools/concurrency_probe.py)
     if (h->overlap_res && !h->sparse && h->lookahead != 0 && h->nblk >= 16)
         CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-    if (const char* e = getenv("IPM_CHAIN_XCD")) h->chain_xcd = atoi(e);
-    if (h->chain_xcd) {
-        hipDeviceProp_t prop;
-        CREATE_TRY(hipGetDeviceProperties(&prop, device));
-        const int ncu = prop.multiProcessorCount;
-        if (ncu >= 64 && ncu % 8 == 0) {
-            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);          // mask bit i <-> XCD i % 8 (tools/prio_probe.hip)
-            for (int i = 0; i < ncu; i += 8) mask[(size_t)i / 32] |= 1u << (i % 32);
-            CREATE_TRY(hipExtStreamCreateWithCUMask(&h->stream_chain, (uint32_t)mask.size(), mask.data()));
-            CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        }
-    }
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
@@ -611,8 +595,6 @@ extern "C" int ipm_destroy(ipm_handle* h) {
         for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
-    if (h->stream_chain) { (void)hipStreamSynchronize(h->stream_chain); (void)hipStreamDestroy(h->stream_chain); }
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->ev_res) (void)hipEventDestroy(h->ev_res);
     if (h->ev_grp) (void)hipEventDestroy(h->ev_grp);
@@ -1441,12 +1423,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         }
         h->last_gs = (gs == 1 && head > 0) ? 2 : gs;
     }
-    const bool own_chain = la && h->stream_chain != nullptr;
-    hipStream_t sm = own_chain ? h->stream_chain : h->stream, sb = la ? h->stream2 : h->stream;
-    if (own_chain) {
-        HIP_TRY(h, hipEventRecord(h->ev_join, h->stream));
-        HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_join, 0));
-    }
+    hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
     // device-polled hand-offs only while this is the one live handle on the device (see g_live)
     const bool alone = h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
     const bool fs = la && h->flag_sync != 0 && alone;
@@ -1614,10 +1591,6 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
     }
     if (la) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_bulk[h->nblk - 2], 0));
-    if (own_chain) {
-        HIP_TRY(h, hipEventRecord(h->ev_join, sm));
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    }
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }
@@ -1644,6 +1617,9 @@ static int ff_build(ipm_handle* h) {
         // spin bounds), with 240 / 232 in 1 of 6 / 5 of 8 runs, with 224 never -- the dispatcher deals workgroups to XCDs
         // and engines round-robin without regard to where the free CUs are, so EVERY engine needs a free one.
         h->ff_workers = std::max(8, prop.multiProcessorCount - prop.multiProcessorCount / 8);
+        // chain_mode 1: ONE launch of as many workgroups as there are CUs (dealt evenly whatever the dispatcher's rotation); the chain
+        // and the four strips of its critical products are roles of that launch, everybody else works
+        if (h->ff_chain_mode) h->ff_workers = std::max(8, prop.multiProcessorCount - 1 - FF_CRIT_WGS);
     }
     const int nstages = (int)(h->np / FF_PBK);               // BK = 16 stages of the pair engine
     const int Q = std::max(1, std::min(h->ff_q, nstages));
@@ -1673,7 +1649,7 @@ static int ff_build(ipm_handle* h) {
         for (int i = 0; i < h->nblk; ++i)
             for (int c = 0; c <= i; ++c) {
                 const size_t t = (size_t)ff_tile(i, c);
-                if (fcnt[t] != h->ff_sched.tile_q[t] || base[t] != 1 || applied[t] != ff_limit(i, c, h->ff_chain_mode) || paneled[t] != (ff_needs_panel(i, c, h->ff_chain_mode) ? 1 : 0))
+                if (fcnt[t] != h->ff_sched.tile_q[t] || base[t] != 1 || applied[t] != ff_limit(i, c) || paneled[t] != (ff_needs_panel(i, c) ? 1 : 0))
                     return fail(h, IPM_ERR_INVALID_ARG, "fused factor: internal error (tile %d,%d incomplete in the work list)", i, c);
             }
     }
@@ -1717,12 +1693,31 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     unsigned* timeout = h->d_flags + 2 * (size_t)nblk;
     HIP_TRY(h, hipMemsetAsync(F, 0, sizeof(unsigned) * h->ff_flag_words, sw));
     HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
-    HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
-    // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
-    // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
-    // formation chunks -- the first diagonal tile is not ready before those are done anyway
-    hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
-                       &h->sc->maxdiag, done);
+    if (!h->ff_chain_mode) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
+    long long* ctrace = h->ff_trace ? h->ff_trace + 4 * h->ff_sched.items.size() : nullptr;
+    FFRoles roles;
+    memset(&roles, 0, sizeof roles);
+    if (h->ff_chain_mode) {
+        // the pivot chain and its two small products are ROLES of the one persistent launch (claimed by arrival); max diag(B)
+        // comes from the FF_D items at the head of the work list
+        FFChain& c = roles.chain;
+        c.B = h->B; c.ldb = h->mp; c.invD = h->invD;
+        c.maxbits = (const unsigned long long*)(F + 8); c.dcount = F + 10; c.maxdiag_out = &h->sc->maxdiag;
+        c.dready = dready; c.potrfdone = potrfdone; c.timeout = timeout; c.dbg = dbg; c.trace = ctrace;
+        c.eps = h->opt.pivot_guard_eps; c.big = h->opt.pivot_guard_big; c.shift_rel = h->shift_rel;
+        c.fixed = &h->sc->fixed; c.done = done; c.nblk = nblk; c.m = (int)h->m;
+        FFCrit& cc = roles.crit;
+        cc.B = h->B; cc.ldb = h->mp; cc.invD = h->invD; cc.tprog = tprog; cc.tile_items = h->d_ff_tile_items;
+        cc.potrfdone = potrfdone; cc.lfinal = lfinal; cc.dready = dready; cc.timeout = timeout; cc.dbg = dbg; cc.trace = ctrace;
+        cc.done = done; cc.nblk = nblk;
+        roles.role = F + 3;
+    } else {
+        // the pivot guard's scale max diag(B) over the true rows, straight from A and d (B is complete only at the very end
+        // here): on the chain's stream in front of potrf_diag(0), i.e. on the CUs the workers leave free, beside their first
+        // formation chunks -- the first diagonal tile is not ready before those are done anyway
+        hipLaunchKernelGGL(ff_maxdiag_kernel, dim3(256), dim3(256), 0, sm, h->A, h->np, (int)h->m, (int)h->np, h->d, h->ff_part, mticket,
+                           &h->sc->maxdiag, done);
+    }
     FFArgs a;
     memset(&a, 0, sizeof a);
     a.A = h->A; a.lda = h->np; a.d = h->d; a.B = h->B; a.ldb = h->mp; a.invD = h->invD; a.slab = h->ff_slab;
@@ -1731,19 +1726,47 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     a.timeout = timeout; a.dbg = dbg; a.done = done;
     { static const bool dbg_on = getenv("IPM_FF_DEBUG") != nullptr; a.dbg_words = dbg_on ? (unsigned)h->ff_flag_words : 0u; }
     a.trace = h->ff_trace;
-    long long* ctrace = h->ff_trace ? h->ff_trace + 4 * h->ff_sched.items.size() : nullptr;
     a.prof = h->ff_prof;
     a.tile_q = h->d_ff_tile_items + ntile;
+    a.maxbits = (unsigned long long*)(F + 8); a.dcount = F + 10;
     a.nblk = nblk; a.Q = h->ff_qmax; a.nstages = (int)(h->np / FF_PBK); a.m = (int)h->m;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], sw));
     {
-        const dim3 grid((unsigned)h->ff_workers);
-        if (a.prof || a.trace) hipLaunchKernelGGL((form_factor_kernel<true>), grid, dim3(FF_THREADS), 0, sw, a);
-        else hipLaunchKernelGGL((form_factor_kernel<false>), grid, dim3(FF_THREADS), 0, sw, a);
+        if (h->ff_chain_mode) {
+            const dim3 grid((unsigned)h->ff_workers + 1u + (unsigned)FF_CRIT_WGS);
+            if (a.prof || a.trace) hipLaunchKernelGGL((form_factor_roles_kernel<true>), grid, dim3(FF_THREADS), 0, sw, a, roles);
+            else hipLaunchKernelGGL((form_factor_roles_kernel<false>), grid, dim3(FF_THREADS), 0, sw, a, roles);
+        } else {
+            const dim3 grid((unsigned)h->ff_workers);
+            if (a.prof || a.trace) hipLaunchKernelGGL((form_factor_kernel<true>), grid, dim3(FF_THREADS), 0, sw, a);
+            else hipLaunchKernelGGL((form_factor_kernel<false>), grid, dim3(FF_THREADS), 0, sw, a);
+        }
     }
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], sw));
     HIP_TRY(h, hipGetLastError());
     h->n_counter_steps = 0; h->n_event_steps = 0; h->last_gs = 1;
+    if (h->ff_chain_mode) {
+        // Everything the residual stream does -- the inverses of the complete 1024-row groups, r_b, r_c, the stop test, the
+        // predictor's right-hand side -- sits behind a GATE that opens when the chain has factored block `gate_step`: no stream
+        // event can mark a point inside the persistent launch, and every CU is taken until the workers leave, which they do from
+        // about that step on (all items drawn).  Enqueued after the launch; ev_res joins it into the main stream as before.
+        h->n_counter_steps = nblk;
+        const int gate_step = ginv_step >= 0 ? ginv_step : mid_step;
+        if (gate_step >= 0) {
+            HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_fork, 0));            // (the hand-off words are zeroed)
+            hipLaunchKernelGGL(ff_gate_kernel, dim3(1), dim3(64), 0, h->stream3, potrfdone + gate_step, 1u, timeout, done);
+            if (ginv_step >= 0) { int rc_ = enqueue_group_inverses(h, 0, (ginv_step + 1) / h->gsz, h->stream3); if (rc_) return rc_; }
+            if (mid_step >= 0) {
+                int rc_ = enqueue_residuals(h, h->stream3);
+                if (rc_) return rc_;
+                launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1, h->stream3);   // predictor rhs = -r_b - A (d*t)
+                HIP_TRY(h, hipEventRecord(h->ev_res, h->stream3));
+            }
+        }
+        HIP_TRY(h, hipGetLastError());
+        h->ff_last = true;
+        return IPM_OK;
+    }
     for (int k = 0; k < nblk; ++k) {
         PotrfDiag pd;
         pd.Bkk = h->B + (int64_t)k * NB * (h->mp + 1); pd.ld = h->mp;
@@ -2432,7 +2455,7 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     // on: one hipGraphLaunch instead of ~100 launches per iteration.  One stream, no events, no device polling inside the capture; every kernel still
     // tests Scalars::done, so replaying past convergence is the same no-op as enqueueing past it.
     struct GraphGuard { hipGraphExec_t exec = nullptr; ~GraphGuard() { if (exec) (void)hipGraphExecDestroy(exec); } } gg;
-    const bool graph_ok = h->use_graph != 0 && !h->spf && h->stream2 == nullptr && h->stream3 == nullptr && h->stream_chain == nullptr && h->nblk > 1;
+    const bool graph_ok = h->use_graph != 0 && !h->spf && h->stream2 == nullptr && h->stream3 == nullptr && h->nblk > 1;
     int chunk_idx = 0;
     for (;;) {
         // roll-back point: the first chunk (auto-regularize restart) and every chunk that can hit a poll time-out

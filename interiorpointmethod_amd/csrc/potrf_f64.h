@@ -381,15 +381,10 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
     return nfix;
 }
 
+// One diagonal block: wait for it (optional), factor it in the LDS workspace W, write L_kk and inv(L_kk), signal (optional).
+// The body of potrf_diag_kernel and of every step of ff_chain_kernel (form_factor.h).
 template <bool STAMP>
-__global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
-    if (a.done && *a.done) {
-        if (a.signal && threadIdx.x == 0) __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    __shared__ __attribute__((aligned(16))) double W[NB * WLD];
-    __shared__ double dinv_s[NB];
-
+__device__ __forceinline__ void potrf_diag_body(const PotrfDiag& a, double* W, double* dinv_s) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.trace && tid == 0) a.trace[0] = (long long)wall_clock64();
@@ -487,6 +482,17 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
         }
     }
     if (a.trace && tid == 0) a.trace[2] = (long long)wall_clock64();
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
+    if (a.done && *a.done) {
+        if (a.signal && threadIdx.x == 0) __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) double W[NB * WLD];
+    __shared__ double dinv_s[NB];
+    potrf_diag_body<STAMP>(a, W, dinv_s);
 }
 
 // max of the diagonal of an n x n matrix (single workgroup; n <= a few 10^4)

@@ -15,6 +15,7 @@ class Model:
     f_over, f_stage = 17.9, 3.91          # F chunk: us fixed + per BK=16 stage
     t_over, t_col, t_base, t_panel, t_rmw = 4.1, 15.8, 53.0, 21.0, 2.0
     gap = 0.8                             # end of an item -> next ticket drawn
+    d_item = 140.0
     potrf, cpanel, cupdate = 36.0, 8.0, 5.0
     g_potrf_panel, g_panel_update, g_update_potrf = 3.5, 3.5, 4.0
     chain_start = 220.0                   # ff_maxdiag in front of potrf(0)
@@ -25,7 +26,7 @@ def tile_id(i, c):
     return i * (i + 1) // 2 + c
 
 
-def replay(items, nblk, W=224, M=Model, tile_q=None, verbose=False):
+def replay(items, nblk, W=224, M=Model, tile_q=None, verbose=False, mode=0):
     """items: (n, 8) uint8 FFItem records.  Returns dict(end, chain potrf start times, worker busy/wait sums, per-item times)."""
     n = len(items)
     typ = items[:, 0]; ti = items[:, 1].astype(int); tc = items[:, 2].astype(int)
@@ -55,7 +56,8 @@ def replay(items, nblk, W=224, M=Model, tile_q=None, verbose=False):
     heapq.heapify(free)
     # The chain depends on items and items on the chain: process items in list order (each item's start only depends on
     # EARLIER items and on the chain, which only depends on earlier items) and advance the chain lazily.
-    chain = {"k": 0, "phase": 0, "free": M.chain_start}
+    chain = {"k": 0, "phase": 0, "free": M.chain_start if mode == 0 else 0.0}
+    dcount = {"n": 0, "t": 0.0}
 
     def advance_chain():
         while chain["k"] < nblk:
@@ -63,7 +65,9 @@ def replay(items, nblk, W=224, M=Model, tile_q=None, verbose=False):
             if chain["phase"] == 0:
                 if dready[k] == INF:
                     return
-                st = max(chain["free"], dready[k] + M.handoff)
+                if mode and k == 0 and dcount["n"] < nblk:
+                    return
+                st = max(chain["free"], dready[k] + M.handoff, dcount["t"] + M.handoff if mode else 0.0)
                 potrf_start[k] = st
                 potrf_done[k] = st + M.potrf
                 chain["free"] = potrf_done[k] + M.g_potrf_panel
@@ -100,6 +104,12 @@ def replay(items, nblk, W=224, M=Model, tile_q=None, verbose=False):
     for k in range(n):
         t0, w = heapq.heappop(free)
         t_draw[k] = t0; who[k] = w
+        if typ[k] == 2:                      # FF_D
+            e = t0 + M.d_item
+            dcount["n"] += 1; dcount["t"] = max(dcount["t"], e)
+            t_ready[k] = t0; t_end[k] = e
+            heapq.heappush(free, (e + M.gap, w))
+            continue
         if typ[k] == FF_F:
             e = t0 + M.f_over + M.f_stage * max(0, s1[k] - s0[k])
             for r in (ti[k], ti[k] + 1):
@@ -133,14 +143,15 @@ def replay(items, nblk, W=224, M=Model, tile_q=None, verbose=False):
             lfin[ti[k]][tc[k]] = e
         tprog_time[(t, seq[k])] = e
         if fl[k] & SIG0:
-            dready[0] = e
+            dready[ti[k]] = e
         t_ready[k] = rdy; t_end[k] = e
         heapq.heappush(free, (e + M.gap, w))
     advance_chain()
     T = typ == FF_T
+    Fm = typ == FF_F
     return {"end": max(potrf_done[nblk - 1], t_end.max()), "chain_end": potrf_done[nblk - 1], "potrf_start": potrf_start,
-            "form_end": t_end[typ == FF_F].max(), "wait_sum": float((t_ready[T] - t_draw[T]).sum()),
-            "t_work": float((t_end[T] - t_ready[T]).sum()), "f_work": float((t_end[~T] - t_draw[~T]).sum()),
+            "form_end": t_end[Fm].max(), "wait_sum": float((t_ready[T] - t_draw[T]).sum()),
+            "t_work": float((t_end[T] - t_ready[T]).sum()), "f_work": float((t_end[Fm] - t_draw[Fm]).sum()),
             "t_draw": t_draw, "t_ready": t_ready, "t_end": t_end, "who": who}
 
 

@@ -99,7 +99,7 @@ def analyse(tr, items, nit, nblk, out=sys.stdout):
     for n_ in range(nit):
         if it[n_, 0] <= 0:
             continue
-        if F[n_]:
+        if not T[n_]:
             add(binsF, it[n_, 0], it[n_, 2])
         else:
             add(binsW, it[n_, 0], it[n_, 1]); add(binsT, it[n_, 1], it[n_, 2])

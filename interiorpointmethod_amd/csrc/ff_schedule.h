@@ -32,6 +32,7 @@
 #include <limits>
 #include <queue>
 #include <set>
+#include <string>
 #include <vector>
 
 namespace ipm {
@@ -82,6 +83,13 @@ struct FFModel {                       // durations in microseconds, calibrated 
                                        // finish their chunks in lockstep
     int nstages = 512;                 // K / 16 of the formation
     int q_last = 0;                    // > 0: chunks per pair for the pairs of the last two block rows (shorter chunks pack the end)
+    // calibration of chain_mode 1 (profiles/r04_ff_item_trace_roles_kernel.txt: the replay of the list under these values ends
+    // at 3347 us, the launch it models at 3355 us)
+    void roles_calibration() {
+        chain_mode = 1;
+        f_over = 6.1; f_stage = 4.02; t_over = 7.0; t_col = 15.9; t_rmw = 1.0; t_panel = 18.3; t_base = 6.75; d_item = 130.0;
+        potrf = 36.8; cpanel = 7.3; cupdate = 7.3; handoff = 1.0; chain_start = 0.0;
+    }
 };
 
 struct FFSchedule {
@@ -111,6 +119,23 @@ inline void ff_build_schedule(int nblk, int Q, int W, const FFModel& M_in, FFSch
     if (const char* e = getenv("IPM_FF_TAIL")) Mx.tail = std::max(1, atoi(e));
     if (const char* e = getenv("IPM_FF_STAGGER")) Mx.stagger = std::min(0.9, std::max(0.0, atof(e)));
     if (const char* e = getenv("IPM_FF_Q_LAST")) Mx.q_last = std::max(0, atoi(e));
+    if (const char* e = getenv("IPM_FF_MODEL")) {             // tuning aid: "name=value,name=value" over the durations above
+        std::string spec(e);
+        size_t p0 = 0;
+        while (p0 < spec.size()) {
+            size_t p1 = spec.find(',', p0); if (p1 == std::string::npos) p1 = spec.size();
+            const std::string kv = spec.substr(p0, p1 - p0);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) {
+                const std::string k = kv.substr(0, eq); const double v = atof(kv.c_str() + eq + 1);
+                struct { const char* n; double* p; } tab[] = {{"f_over", &Mx.f_over}, {"f_stage", &Mx.f_stage}, {"t_over", &Mx.t_over}, {"t_col", &Mx.t_col},
+                    {"t_rmw", &Mx.t_rmw}, {"t_panel", &Mx.t_panel}, {"t_base", &Mx.t_base}, {"d_item", &Mx.d_item}, {"potrf", &Mx.potrf},
+                    {"cpanel", &Mx.cpanel}, {"cupdate", &Mx.cupdate}, {"handoff", &Mx.handoff}, {"gap", &Mx.gap}};
+                for (auto& t : tab) if (k == t.n) *t.p = v;
+            }
+            p0 = p1 + 1;
+        }
+    }
     const FFModel& M = Mx;
     const int mode = M.chain_mode;
     enum Kind { K_F, K_T, K_D, K_POTRF, K_CPANEL, K_CUPDATE };

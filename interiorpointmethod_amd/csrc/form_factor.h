@@ -72,8 +72,8 @@ __device__ __forceinline__ void ff_wait_ge(const unsigned* p, unsigned v, unsign
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) {
         __builtin_amdgcn_s_sleep(2);
         ++spins;
-        if (spins > (1u << 22) || ((spins & 1023u) == 1u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            if (spins > (1u << 22) && dbg && __hip_atomic_fetch_add(dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        if (spins > ipm_spin_limit || ((spins & 1023u) == 1u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (spins > ipm_spin_limit && dbg && __hip_atomic_fetch_add(dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 dbg[1] = item; dbg[2] = kind; dbg[3] = v; dbg[4] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // snapshot of every hand-off word BEFORE the time-out word releases the other waiters (dbg[5] = words, the
                 // copy sits right behind the live words)
@@ -512,17 +512,32 @@ __device__ __forceinline__ void form_factor_body(const FFArgs& g, const FFRoles*
             // ---- diag(B) of the true rows of block ti straight from A and d -> running maximum (the pivot guard's scale): one
             //      wave per row, 16 rows per wave; max of non-negative doubles through their bit patterns (order independent)
             double mx = 0.0;
+            const int ncols = g.nstages * FF_PBK;
             for (int rr = wave; rr < 128; rr += 8) {
                 const int row = ti * 128 + rr;
                 if (row >= g.m) break;
                 const double* a = g.A + (int64_t)row * g.lda;
-                double sacc = 0.0;
-                for (int kq = lane * 2; kq < g.nstages * FF_PBK; kq += 128) {
+                // four independent partial sums, eight 16-byte loads in flight per lane (one dependent FMA chain per row made an
+                // item 400 us: 8 MB at 20 GB/s)
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int kq = lane * 2;
+                for (; kq + 384 < ncols; kq += 512) {
+                    const f64x2 a0 = *reinterpret_cast<const f64x2*>(a + kq), a1 = *reinterpret_cast<const f64x2*>(a + kq + 128);
+                    const f64x2 a2 = *reinterpret_cast<const f64x2*>(a + kq + 256), a3 = *reinterpret_cast<const f64x2*>(a + kq + 384);
+                    const f64x2 d0 = *reinterpret_cast<const f64x2*>(g.d + kq), d1 = *reinterpret_cast<const f64x2*>(g.d + kq + 128);
+                    const f64x2 d2 = *reinterpret_cast<const f64x2*>(g.d + kq + 256), d3 = *reinterpret_cast<const f64x2*>(g.d + kq + 384);
+                    s0 = __builtin_fma(a0.x * a0.x, d0.x, s0); s0 = __builtin_fma(a0.y * a0.y, d0.y, s0);
+                    s1 = __builtin_fma(a1.x * a1.x, d1.x, s1); s1 = __builtin_fma(a1.y * a1.y, d1.y, s1);
+                    s2 = __builtin_fma(a2.x * a2.x, d2.x, s2); s2 = __builtin_fma(a2.y * a2.y, d2.y, s2);
+                    s3 = __builtin_fma(a3.x * a3.x, d3.x, s3); s3 = __builtin_fma(a3.y * a3.y, d3.y, s3);
+                }
+                for (; kq < ncols; kq += 128) {
                     const f64x2 va = *reinterpret_cast<const f64x2*>(a + kq);
                     const f64x2 vd = *reinterpret_cast<const f64x2*>(g.d + kq);
-                    sacc = __builtin_fma(va.x * va.x, vd.x, sacc);
-                    sacc = __builtin_fma(va.y * va.y, vd.y, sacc);
+                    s0 = __builtin_fma(va.x * va.x, vd.x, s0);
+                    s0 = __builtin_fma(va.y * va.y, vd.y, s0);
                 }
+                double sacc = (s0 + s1) + (s2 + s3);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
                 mx = (sacc > mx) ? sacc : mx;            // NaN never wins
@@ -621,6 +636,8 @@ __device__ __forceinline__ void form_factor_body(const FFArgs& g, const FFRoles*
         }
         if (flags & FF_ADD_BASE) {
             const int qn = g.tile_q[tile];
+            // (a second register set that keeps slab c + 1 in flight while slab c is added was tried: the kernel then spills 483
+            //  VGPRs -- the worker loop sits at the register limit)
             for (int c = 0; c < qn; ++c) {
                 const double* sb = g.slab + ((size_t)tile * g.Q + c) * (128 * 128) + (size_t)(wm * 2 + (wn >> 1)) * 4096 + lane * 2;
 #pragma unroll

@@ -27,6 +27,11 @@
 
 namespace ipm {
 
+// Bound of every device-side hand-off spin (polls of ~0.2 us: about 0.7 s).  A wait that runs into it sets the handle's time-out
+// word; the host rolls the call back and repeats it on a path that does not poll.  TEST KNOB: the environment variable
+// IPM_TEST_SPIN_LIMIT (read at ipm_create) lowers it so that the recovery paths can be driven on purpose (tests only).
+__device__ unsigned ipm_spin_limit = 1u << 22;
+
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -271,9 +276,9 @@ void gemm_nt_f64_kernel(GemmNT g) {
                 ++spins;
                 // give up (no hang; the host rolls the call back and repeats it with stream events): after ~1 s of
                 // waiting, or at once when an earlier poll of this call already gave up
-                if (spins > (1u << 22) || ((spins & 1023u) == 1u && g.timeout &&
+                if (spins > ipm_spin_limit || ((spins & 1023u) == 1u && g.timeout &&
                                            __hip_atomic_load(g.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (spins > (1u << 22) && g.dbg && __hip_atomic_fetch_add(g.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    if (spins > ipm_spin_limit && g.dbg && __hip_atomic_fetch_add(g.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                         g.dbg[1] = g.dbg_tag; g.dbg[2] = 6u; g.dbg[3] = g.wait_count;
                         g.dbg[4] = __hip_atomic_load(g.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }

@@ -21,7 +21,6 @@
 #include "gemm_nt_f64.h"
 #include "adat_syrk_f64.h"
 #include "chol_update_f64.h"
-#include "chol_crit_f64.h"
 #include "potrf_f64.h"
 #include "sparse_ops.h"
 #include "trsv_grouped.h"
@@ -56,11 +55,6 @@ struct ipm_handle {
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
     hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr, ev_last = nullptr;
     int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
-    int use_graph = 0;                        // IPM_GRAPH=1: single-stream handles replay captured chunks of iterations.  Measured:
-                                              // host enqueue time of a solve 94 -> 11 ms, but the 73-LP suite with 8-12 LPs in flight is
-                                              // no faster (3.8-4.4 s either way: GPU-side queueing, not launches, bounds it), and while a
-                                              // capture is open ANY legacy-stream call of ANOTHER host thread fails ("would make the legacy
-                                              // stream depend on a capturing blocking stream") -- not something a drop-in library may cause
     int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
     int residual_step = -1;                   // factorization step at which the residual stream starts (-1: 13/16 nblk; IPM_RESIDUAL_STEP)
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
@@ -69,29 +63,14 @@ struct ipm_handle {
     int grouped_trsv = 1;                 // group inverses + GEMV solves (trsv_grouped.h); IPM_GROUPED_TRSV=0 disables
     int gsz = 0;                          // 128-blocks per group: 8 from 16 blocks on (ragged: leftover blocks are solved step by step), else the largest of 8/4/2 dividing nblk
     double *gXT = nullptr, *gX = nullptr, *gS = nullptr, *gPart = nullptr;   // own allocation
-    int persistent_trsv = 0;              // 1: one launch per substitution (measured SLOWER on MI355X: a flagged
-                                          // hand-off costs ~6 us per step vs ~4 us for a kernel boundary); kept as an option
     unsigned* d_bulk_done = nullptr;      // [nblk] workgroup-completion counters of the bulk trailing updates
     bool no_dense = false;                // B / invD / slab are not in the workspace (layout_no_dense); B_own, invD_own once ensure_dense_B ran
     double* B_own = nullptr; double* invD_own = nullptr;
     int group_steps = 0;                  // > 0: forced group size of the two-level schedule
-    int ginv_variant = 1;                 // group-inverse GEMMs: 0 = 64x64 tiles, 1 = 32x32 tiles (4x the workgroups: 0.17 -> 0.12 ms), 2 = 32x32 for the two upper levels
     int two_level = 1;                    // group the Cholesky steps: K = 128*gs trailing updates (IPM_TWO_LEVEL=0 disables)
-    int trsv_multi = 0;                   // IPM_TRSV_MULTI=1: block-step substitutions four steps per launch (every workgroup recomputes the group's solution
-                                          // blocks, next block prefetched: bitwise equal, a third of the launches).  No gain: a step kernel is two block
-                                          // products (~6 us), the recomputation makes a 4-step launch 14 of them -- BNL2 1.556 / 1.549, FINNIS 0.440 / 0.479 ms
-                                          // per iteration on a single-stream handle, the batched suite within noise
-    int la_small_blocks = 0;              // look-ahead handles: trailing blocks up to which the bulk stream uses the narrow-tile kernels (IPM_LA_SMALL_TILES).
-                                          // Off: a lone LP is bound by its pivot chain, not by the bulk stream (DEGEN3 0.94, BNL2 1.63, 25FV47 0.70 ms per
-                                          // iteration for 0 / 8 / 16 / 32 blocks alike; PILOT87 2.34 -> 2.49 -> 2.67 at 16 / 32)
+    int bulk_variant = 0;                 // 0: chol_update_kernel (adat_syrk schedule, round 3); 7: the generic kernel of rounds 1-2 (bit-identical, tested)
     int ss_small_blocks = 16;             // single-stream handles: trailing blocks up to which the narrow-tile panel / update kernels are used (73-LP suite, 8 in flight:
                                           // 12.4 / 13.5 / 14.1 / 14.5 / 14.4 LPs/s for 0 / 4 / 8 / 16 / 64 blocks)
-    int ss_tiny_blocks = 0;               // ... and up to which the update runs on 32 x 32 tiles (IPM_SS_TINY_TILES)
-    int bulk_variant = 0;                 // 0: chol_update_kernel (adat_syrk schedule, round 3); 7: the generic kernel of rounds 1-2; 1: BK=32 tiles (measured slower: 2.38 vs 2.26 ms)
-    int crit_variant = 1;                 // critical-path GEMMs: 1 = 32-row tiles of the generic kernel, 0 = its plain tiles,
-                                          // 2 = single-stage register kernels (chol_crit_f64.h; measured SLOWER: their
-                                          // fragment-shaped 8-byte loads take 7.4 us, profiles/r02_crit_probe.log)
-    int group_head = -1;                  // leading steps factored in pairs (two-level) before the one-level tail; -1 = auto
     int flag_sync = 1;                    // main stream polls d_bulk_done instead of waiting on a stream event
     int last_gs = 1, n_counter_steps = 0, n_event_steps = 0, timeouts_recovered = 0;   // ipm_get_schedule
     bool counted = false;                 // this handle is in g_live
@@ -147,12 +126,12 @@ struct ipm_handle {
     // fused formation + factorization (form_factor.h): dense handles of FF_MIN_NBLK .. FF_MAX_NBLK blocks that have the device to
     // themselves run ONE persistent worker launch beside the pivot chain instead of formation followed by factorization
     int ff_enabled = 1;                   // IPM_FUSED_FACTOR=0 disables, =force also below FF_MIN_NBLK blocks (tests)
-    // Where the fused launch is the default.  Measured on MI355X, it/s fused / serial (tools/ff_sizes.sh, n = 2m unless noted):
-    // 2048: 595 / 646 -- 2560: 396 / 386 -- 3072: 379 / 301 -- 3584: 232 / 211 -- 4096: 216-218 / 206 -- 5120: 124 / 111 --
-    // 4096 x 4608: 299 / 262 -- 4096 x 16384: 128 / 140 (the formation dominates there, and 224 workers form slower than the
-    // serial kernel on all 256 CUs).  So: from 20 blocks on, up to 40 (beyond ~48 the two-level serial schedule is the measured
-    // default), and only while n <= 3 m.  IPM_FF_MAX_NBLK / IPM_FUSED_FACTOR=force|0 override.
-    int ff_min_nblk = 20, ff_max_nblk = 40;
+    // Where the fused launch is the default.  Measured on MI355X, it/s fused / serial (tools/ff_sizes.sh, profiles/r04_ff_sizes_fused_vs_serial.txt;
+    // n = 2m unless noted): 1536: 903 / 941 -- 2048: 684 / 640 -- 2560: 514 / 439 -- 3072: 422 / 302 -- 3584: 335 / 242 -- 4096: 259 / 208 --
+    // 5120: 150 / 113 -- 6144: 93.3 / 79.6 -- 8192: 41.8 / 40.0 -- 10240: 22.3 / 22.4 -- 4096 x 4608: 358 / 267 -- 4096 x 16384: 152 / 137 --
+    // 4096 x 32768: 85.5 / 87.1 (the formation dominates there and the serial kernel forms faster).  So: 16 .. 72 blocks while n <= 6 m.
+    // IPM_FF_MAX_NBLK / IPM_FUSED_FACTOR=force|0 override.
+    int ff_min_nblk = 16, ff_max_nblk = 72;
     bool ff_forced = false;
     int ff_chain_mode = 1;                // FFModel::chain_mode (IPM_FF_CHAIN_MODE): 1 = the pivot chain as roles of the ONE persistent launch (default), 0 = three launches per step on a second stream beside 7/8 of the CUs
     int ff_q = 4;                         // formation chunks per tile (IPM_FF_Q)
@@ -389,6 +368,7 @@ __global__ void set_params_kernel(Scalars* sc, double e1, double e2, double e3, 
 }
 
 static void free_sparse_factor(ipm_handle* h);
+static void ff_release(ipm_handle* h);
 extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* opts, void* workspace,
                           size_t workspace_bytes, void* stream, ipm_handle** out) {
     if (!out) return fail(nullptr, IPM_ERR_INVALID_ARG, "out is NULL");
@@ -471,6 +451,12 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->d_colind = (int*)(base + L.off_colind); h->d_rowind = (int*)(base + L.off_rowind);
     h->d_rval = (double*)(base + L.off_rval); h->d_cval = (double*)(base + L.off_cval);
     if (const char* e = getenv("IPM_FORM_VARIANT")) h->form_variant = atoi(e);
+    {   // test knob (see gemm_nt_f64.h): spin bound of the device-side hand-offs; set in every case, so that a later handle restores the default
+        unsigned lim = 1u << 22;
+        if (const char* e = getenv("IPM_TEST_SPIN_LIMIT")) lim = (unsigned)std::max(1, atoi(e));
+        CREATE_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(ipm_spin_limit), &lim, sizeof lim, 0, hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream));
+    }
     if (const char* e = getenv("IPM_ENVELOPE")) h->envelope = atoi(e);
     // zero everything except A and B (padding entries of every vector must stay 0)
     CREATE_TRY(hipMemsetAsync(base + L.off_inv, 0, L.off_slab - L.off_inv, h->stream));
@@ -482,10 +468,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     memset(h->h_sc, 0, sizeof(Scalars));
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
-    if (const char* e = getenv("IPM_GRAPH")) h->use_graph = atoi(e);
     if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
     if (h->opt.flags & IPM_FLAG_SINGLE_STREAM) h->lookahead = 0;
-    if (const char* e = getenv("IPM_PERSISTENT_TRSV")) h->persistent_trsv = atoi(e);
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
     if (h->no_dense) h->grouped_trsv = 0;      // the sparse factor has its own sweeps; a dense entry point on such a handle solves block by block
     h->gsz = 0;
@@ -521,16 +505,10 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipMemsetAsync(h->d_bulk_done, 0, sizeof(unsigned) * (2 * (size_t)h->nblk + 4), h->stream));
     if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
     if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
-    if (const char* e = getenv("IPM_CRIT_VARIANT")) h->crit_variant = atoi(e);
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
     if (const char* e = getenv("IPM_SS_SMALL_TILES")) h->ss_small_blocks = atoi(e);
-    if (const char* e = getenv("IPM_LA_SMALL_TILES")) h->la_small_blocks = atoi(e);
-    if (const char* e = getenv("IPM_TRSV_MULTI")) h->trsv_multi = atoi(e);
-    if (const char* e = getenv("IPM_SS_TINY_TILES")) h->ss_tiny_blocks = atoi(e);
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
-    if (const char* e = getenv("IPM_GINV_VARIANT")) h->ginv_variant = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
-    if (const char* e = getenv("IPM_GROUP_HEAD")) h->group_head = atoi(e);
     if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
     if (const char* e = getenv("IPM_LIST_FORM")) h->list_form_opt = atoi(e);
     if (getenv("IPM_POTRF_STAMPS")) { CREATE_TRY(dev_malloc(device, h->stream, (void**)&h->stamp_buf, 8 * 64 * sizeof(long long))); CREATE_TRY(hipMemsetAsync(h->stamp_buf, 0, 8 * 64 * sizeof(long long), h->stream)); }
@@ -604,9 +582,9 @@ extern "C" int ipm_destroy(ipm_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->h_sc) { std::lock_guard<std::mutex> lock(g_hsc_mutex); g_hsc_pool.push_back(h->h_sc); h->h_sc = nullptr; }
-    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->B_own, (void*)h->invD_own, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart,
-                    (void*)h->d_ff_items, (void*)h->d_ff_flags, (void*)h->ff_slab, (void*)h->ff_part, (void*)h->ff_prof, (void*)h->ff_trace, (void*)h->d_ff_tile_items})
+    for (void* p : {(void*)h->stamp_buf, (void*)h->d_flags, (void*)h->d_bulk_done, (void*)h->B_own, (void*)h->invD_own, (void*)h->gXT, (void*)h->gX, (void*)h->gS, (void*)h->gPart})
         dev_free(h->device, h->stream, p);
+    ff_release(h);
     free_sparse_factor(h);
     for (void* p : {(void*)h->sm_bptr, (void*)h->sm_bcol, (void*)h->sm_bi, (void*)h->sm_bk, (void*)h->sm_bcoef, (void*)h->ls_bi, (void*)h->ls_bk, (void*)h->ls_bak})
         dev_free(h->device, h->stream, p);
@@ -1332,15 +1310,7 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
                                     h->d_tile_order, h->stream, h->slab, 512));
         return IPM_OK;
     }
-    switch (h->form_variant) {
-        case 1: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream))); break;               // no split-K
-        case 2: HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(g, h->stream, h->slab, 256))); break;  // BK=32, 1 wg/CU
-        case 3: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(g, h->stream, h->slab, 512))); break;  // 8 waves/wg, 4 waves/SIMD
-        case 4: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(g, h->stream, h->slab, 512))); break;
-        case 5: g.w = nullptr; HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;  // timing probe: no d scaling (WRONG result)
-        case 6: g.tile_order = nullptr; HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;  // timing probe: row-major tile order
-        default: HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512))); break;   // 7: generic kernel (round 1)
-    }
+    HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512)));      // IPM_FORM_VARIANT=7: the generic kernel (round 1; bit-identical, tested)
     return IPM_OK;
 }
 
@@ -1404,25 +1374,14 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         else if (h->nblk >= 96) gs = 4;
         else if (h->nblk >= 48) gs = 3;
     }
-    // Group table.  Uniform groups of gs (>= 48 blocks); below that the HEAD of the factorization -- the steps whose
-    // trailing update (hundreds of tiles, each re-reading and re-writing the trailing matrix) is longer than the pivot
-    // chain -- is factored in pairs and the chain-bound tail one step at a time.
+    // Group table: uniform groups of gs block columns (from 48 blocks on; one-level below that -- pairing only the head of the
+    // factorization was measured and does not pay below 48 blocks either: 2.158 / 2.157 / 2.182 / 2.213 ms for 0 / 4 / 8 / 16 paired steps)
     std::vector<int> grp_lo(h->nblk), grp_hi(h->nblk);
-    {
-        int head = 0;
-        if (gs == 1 && la && !use_env && h->two_level != 0 && h->group_steps <= 0) {
-            // measured at 4096 x 8192 (32 blocks), factor ms for head = 0 / 4 / 8 / 12 / 16 / 20: 2.158 / 2.157 / 2.182 / 2.183 /
-            // 2.213 / 2.251 -- pairing the head does not pay below 48 blocks either, so the default is 0 (IPM_GROUP_HEAD=n)
-            head = h->group_head >= 0 ? h->group_head : 0;
-            head = std::min(head, h->nblk) & ~1;
-        }
-        for (int k = 0; k < h->nblk; ++k) {
-            if (gs > 1) { grp_lo[k] = (k / gs) * gs; grp_hi[k] = std::min(grp_lo[k] + gs, h->nblk); }
-            else if (k < head) { grp_lo[k] = k & ~1; grp_hi[k] = grp_lo[k] + 2; }
-            else { grp_lo[k] = k; grp_hi[k] = k + 1; }
-        }
-        h->last_gs = (gs == 1 && head > 0) ? 2 : gs;
+    for (int k = 0; k < h->nblk; ++k) {
+        if (gs > 1) { grp_lo[k] = (k / gs) * gs; grp_hi[k] = std::min(grp_lo[k] + gs, h->nblk); }
+        else { grp_lo[k] = k; grp_hi[k] = k + 1; }
     }
+    h->last_gs = gs;
     hipStream_t sm = h->stream, sb = la ? h->stream2 : h->stream;
     // device-polled hand-offs only while this is the one live handle on the device (see g_live)
     const bool alone = h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
@@ -1485,8 +1444,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             // latency-shorter kernels -- ss_small_blocks = trailing blocks up to which they are used (IPM_SS_SMALL_TILES)
             if (rem <= h->ss_small_blocks * NB) {
                 HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(t, sm)));
-                if (rem <= h->ss_tiny_blocks * NB) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(u, sm)));
-                else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(u, sm)));
+                HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(u, sm)));
                 continue;
             }
             HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(t, sm)));
@@ -1511,14 +1469,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         if (crit_flag) tc.signal = h->d_bulk_done + h->nblk + k;
         // NOTE the panel solve is IN PLACE (C = P): a workgroup must own whole rows, i.e. BN == N == 128.  Tiles narrower
         // than the panel (tried: 16 workgroups of 32 x 32) race -- one workgroup overwrites columns another still reads.
-        const bool crit_regs = h->crit_variant == 2;         // single-stage register kernels: one memory latency per kernel
-        if (crit_regs) {
-            CritStep cs;
-            cs.panel = panel; cs.ld = h->mp; cs.inv = pd.inv; cs.C = nullptr; cs.ldc = 0; cs.done = done;
-            cs.signal = tc.signal; cs.wait_on = tc.wait_on; cs.wait_count = tc.wait_count; cs.timeout = tc.timeout;
-            hipLaunchKernelGGL(crit_panel_kernel, dim3(NB / 16), dim3(512), 0, sm, cs);
-        } else if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
-        else HIP_TRY(h, (launch_gemm_nt<32, 128, 16, 1, 4>(tc, sm)));
+        HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tc, sm)));     // 8 waves, BK=32: 4 stages
         if (!crit_flag) HIP_TRY(h, hipEventRecord(h->ev_crit[k], sm));
         // Two-level blocking (dense handles): the steps come in groups of `gs` block columns.  A step updates only the
         // remaining columns of its group (a window of K = 128 tiles) and DEFERS the rest of its trailing update; the last
@@ -1533,22 +1484,12 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
             u.P = panel - (int64_t)(k - g0) * NB; u.Q = u.P; u.K = (k - g0 + 1) * NB;
         }
         GemmNT uc = u; uc.M = NB; uc.N = NB;                        // critical tile (k+1,k+1)
-        if (crit_regs && uc.K == NB) {                              // (K > 128: the deferred group update, generic kernel)
-            CritStep cs;
-            cs.panel = const_cast<double*>(uc.P); cs.ld = h->mp; cs.inv = nullptr; cs.C = uc.C; cs.ldc = h->mp; cs.done = done;
-            cs.signal = nullptr; cs.wait_on = nullptr; cs.wait_count = 0; cs.timeout = nullptr;
-            hipLaunchKernelGGL(crit_syrk_kernel, dim3(9), dim3(256), 0, sm, cs);
-        } else if (h->crit_variant) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));      // 10 sub-tiles of 32x32
-        else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(uc, sm)));
+        HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(uc, sm)));      // 10 sub-tiles of 32x32
         if (!crit_flag) HIP_TRY(h, hipStreamWaitEvent(sb, h->ev_crit[k], 0));
         if (rem > NB) {
             GemmNT tb = t; tb.C = panel + (int64_t)NB * h->mp; tb.P = tb.C; tb.M = rem - NB;
-            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = crit_regs ? NB / 16 : NB / 32; tb.timeout = h->d_flags + 2 * (size_t)h->nblk; }   // workgroups of the critical panel launch
-            // few trailing blocks: the bulk side of a step is as long as the chain's (potrf + two small GEMMs); the narrow-tile
-            // kernels of the single-stream path shorten it (la_small_blocks, IPM_LA_SMALL_TILES)
-            const bool la_small = !grouped && rem <= h->la_small_blocks * NB;
-            if (la_small) HIP_TRY(h, (launch_gemm_nt<32, 128, 32, 1, 8>(tb, sb)));
-            else HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
+            if (crit_flag) { tb.wait_on = h->d_bulk_done + h->nblk + k; tb.wait_count = NB / 32; tb.timeout = h->d_flags + 2 * (size_t)h->nblk; }   // workgroups of the critical panel launch
+            HIP_TRY(h, (launch_gemm_nt<64, 128, 16, 2, 2>(tb, sb)));
             GemmNT ub = u;
             const int nt = rem / NB;
             if (grp_inner) {
@@ -1565,15 +1506,6 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
                 HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
                 continue;
             }
-            if (la_small) {                                         // 64 x 64 tiles; the critical 128 x 128 tile = the first three of them
-                const int n64 = rem / 64;
-                const int wgs = n64 * (n64 + 1) / 2 - 3;
-                if (fs) { bulk_wgs[k] = (unsigned)wgs; ub.signal = h->d_bulk_done + k; ++h->n_counter_steps; }
-                else ++h->n_event_steps;
-                HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/3)));
-                HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
-                continue;
-            }
             const int ub_wgs = nt * (nt + 1) / 2 - 1;
             // the per-workgroup release (L2 write-back) of the counter protocol only pays in the latency-bound
             // regime; a throughput-bound update (thousands of tiles: 16k: 40 -> 50 ms) keeps the stream event
@@ -1582,10 +1514,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
                 ub.signal = h->d_bulk_done + k;
                 ++h->n_counter_steps;
             } else ++h->n_event_steps;
-            if (h->bulk_variant == 1) HIP_TRY(h, (launch_gemm_nt<128, 128, 32, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
-            else if (h->bulk_variant == 3) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 4>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // 8 waves per tile
-            else if (h->bulk_variant == 4) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 4, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));
-            else if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // the generic kernel (rounds 1-2)
+            if (h->bulk_variant == 7) HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(ub, sb, nullptr, 512, /*skip_first=*/1)));   // the generic kernel (rounds 1-2)
             else HIP_TRY(h, launch_chol_update(ub, sb, /*skip_first=*/1));
         }
         HIP_TRY(h, hipEventRecord(h->ev_bulk[k], sb));
@@ -1601,7 +1530,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
 static bool ff_ok(const ipm_handle* h) {
     if (!h->ff_enabled || h->sparse || h->lookahead == 0 || h->stream2 == nullptr || h->flag_sync == 0) return false;
     if (h->nblk < h->ff_min_nblk || h->nblk > std::min(h->ff_max_nblk, FF_MAX_NBLK) || h->np % FF_PBK) return false;
-    if (!h->ff_forced && h->np > 3 * h->mp) return false;
+    if (!h->ff_forced && h->np > 6 * h->mp) return false;
     return h->device >= MAX_DEVICES || g_live[h->device].load(std::memory_order_acquire) <= 1;
 }
 
@@ -1625,7 +1554,8 @@ static int ff_build(ipm_handle* h) {
     const int Q = std::max(1, std::min(h->ff_q, nstages));
     h->ff_q = Q;
     FFModel M;
-    M.nstages = nstages; M.chain_mode = h->ff_chain_mode;
+    if (h->ff_chain_mode) M.roles_calibration();
+    M.nstages = nstages;
     ff_build_schedule(h->nblk, Q, h->ff_workers, M, h->ff_sched, std::max(Q, std::min(16, nstages)));
     h->ff_qmax = 1;                                           // slab capacity per tile = the most chunks any tile is formed in
     for (int q_ : h->ff_sched.tile_q) h->ff_qmax = std::max(h->ff_qmax, q_);
@@ -1677,12 +1607,28 @@ static int ff_build(ipm_handle* h) {
     return IPM_OK;
 }
 
+// ff_ok and the schedule + buffers are there.  A failure of ff_build (an allocation, an internal check) is not an error of the
+// solve: what was allocated is freed, the handle stops using the fused launch and the iteration runs formation then factorization.
+static void ff_release(ipm_handle* h) {
+    for (void** p : {(void**)&h->d_ff_items, (void**)&h->d_ff_flags, (void**)&h->ff_slab, (void**)&h->ff_part, (void**)&h->ff_prof, (void**)&h->ff_trace,
+                     (void**)&h->d_ff_tile_items}) { dev_free(h->device, h->stream, *p); *p = nullptr; }
+    h->ff_built = false;
+}
+static bool ff_use(ipm_handle* h) {
+    if (!ff_ok(h)) return false;
+    if (h->ff_built) return true;
+    if (ff_build(h) == IPM_OK) return true;
+    ff_release(h);
+    h->ff_enabled = 0;
+    (void)hipGetLastError();
+    return false;
+}
+
 // One persistent worker launch (formation chunks + every update / panel solve outside the pivot chain) on the main stream and
 // the pivot chain -- potrf_diag(k), panel solve of tile (k+1,k), update of tile (k+1,k+1) -- on the second stream, coupled
 // through device counters only.  `ev` (optional): ev[1] / ev[2] bracket the worker launch.
 static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int ginv_step) {
-    int rc = ff_build(h);
-    if (rc) return rc;
+    if (!h->ff_built) return fail(h, IPM_ERR_STATE, "fused factor: schedule not built");
     const int nblk = h->nblk;
     const size_t ntile = (size_t)nblk * (nblk + 1) / 2;
     const int* done = h->fdone ? h->fdone : &h->sc->done;
@@ -1823,7 +1769,7 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     FFModel M;
     M.nstages = 512;                                          // K = 8192 (the headline size's formation), BK = 16 stages
     if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) M.nstages = std::max(q, atoi(e));
-    if (const char* e = getenv("IPM_FF_CHAIN_MODE")) M.chain_mode = atoi(e) != 0;
+    if (!(getenv("IPM_FF_CHAIN_MODE") && atoi(getenv("IPM_FF_CHAIN_MODE")) == 0)) M.roles_calibration();
     ff_build_schedule(nblk, q, workers, M, S, std::max(q, 16));
     *count = (int32_t)S.items.size();
     if (items) memcpy(items, S.items.data(), sizeof(FFItem) * std::min<size_t>(S.items.size(), (size_t)std::max(0, capacity)));
@@ -1866,7 +1812,6 @@ static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStr
     const double* Lg = h->B + g0 * gL;
     for (int hs = 128; hs < GR; hs *= 2) {
         const int np = (int)(GR / (2 * hs));              // pairs per group
-        const bool small = h->ginv_variant == 1 || (h->ginv_variant == 2 && hs >= 256);   // 32 x 32 tiles: 4x the workgroups
         GemmNT t = gemm_defaults();
         t.tile_order = nullptr; t.w = nullptr; t.done = done; t.lower = 0; t.unit_diag_from = -1;
         t.M = hs; t.N = hs; t.K = hs; t.beta = 0.0; t.batch = np; t.batch2 = nG;
@@ -1877,17 +1822,17 @@ static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStr
         a.P = gXT; a.ldp = GR; a.sP = pX; a.sP2 = gXs;
         a.Q = Lg + (int64_t)hs * h->mp; a.ldq = h->mp; a.sQ = pL; a.sQ2 = gL;
         a.C = gS; a.ldc = hs; a.sC = pS; a.sC2 = gSs; a.alpha = 1.0;
-        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(a, st))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(a, st)));
+        HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(a, st)));      // 32 x 32 tiles (4x the workgroups of 64 x 64: 0.17 -> 0.12 ms)
         GemmNT b = t;                                     // X21 = -X22 * S^T
         b.P = gX + (int64_t)hs * GR + hs; b.ldp = GR; b.sP = pX; b.sP2 = gXs;
         b.Q = gS; b.ldq = hs; b.sQ = pS; b.sQ2 = gSs;
         b.C = gX + (int64_t)hs * GR; b.ldc = GR; b.sC = pX; b.sC2 = gXs; b.alpha = -1.0;
-        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(b, st))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(b, st)));
+        HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(b, st)));
         GemmNT c = t;                                     // XT12 = -S * X22^T
         c.P = gS; c.ldp = hs; c.sP = pS; c.sP2 = gSs;
         c.Q = gX + (int64_t)hs * GR + hs; c.ldq = GR; c.sQ = pX; c.sQ2 = gXs;
         c.C = gXT + hs; c.ldc = GR; c.sC = pX; c.sC2 = gXs; c.alpha = -1.0;
-        if (small) HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(c, st))); else HIP_TRY(h, (launch_gemm_nt<64, 64, 16, 2, 2>(c, st)));
+        HIP_TRY(h, (launch_gemm_nt<32, 32, 32, 2, 2>(c, st)));
     }
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
@@ -1992,36 +1937,6 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
     }
     if (h->grouped_trsv) return enqueue_potrs_grouped(h, r, out, wait_last);
     if (wait_last) HIP_TRY(h, hipStreamWaitEvent(h->stream, wait_last, 0));
-    if (h->persistent_trsv && h->nblk >= 2 && h->nblk <= 240) {
-        // flags: [0,nblk) forward, [nblk,2nblk) backward, then the timeout word; zeroed per call
-        HIP_TRY(h, hipMemsetAsync(h->d_flags, 0, sizeof(unsigned) * (2 * (size_t)h->nblk), h->stream));
-        TrsvPersist p;
-        p.L = h->B; p.ld = h->mp; p.inv = h->invD; p.nblk = h->nblk; p.done = &h->sc->done;
-        p.timeout = h->d_flags + 2 * (size_t)h->nblk;
-        p.rhs = r; p.z = h->t2; p.flags = h->d_flags;
-        hipLaunchKernelGGL(trsv_fwd_persistent_kernel, dim3(h->nblk), dim3(256), 0, h->stream, p);
-        p.rhs = h->t2; p.z = out; p.flags = h->d_flags + h->nblk;
-        hipLaunchKernelGGL(trsv_bwd_persistent_kernel, dim3(h->nblk), dim3(256), 0, h->stream, p);
-        HIP_TRY(h, hipGetLastError());
-        return IPM_OK;
-    }
-    if (h->trsv_multi && !h->use_env && h->nblk >= 2) {
-        // several block steps per launch, every workgroup recomputing the group's solution blocks for itself (no hand-offs)
-        TrsvMulti q;
-        q.L = h->B; q.ld = h->mp; q.inv = h->invD; q.done = &h->sc->done;
-        q.r = r; q.z = h->t2;
-        for (int k0 = 0; k0 < h->nblk; k0 += TRSV_MULTI_G) {
-            q.k0 = k0; q.g = std::min(TRSV_MULTI_G, h->nblk - k0);
-            hipLaunchKernelGGL(trsv_fwd_multi_kernel, dim3(h->nblk - k0), dim3(256), 0, h->stream, q);
-        }
-        q.r = h->t2; q.z = out;
-        for (int k0 = h->nblk - 1; k0 >= 0; k0 -= TRSV_MULTI_G) {
-            q.k0 = k0; q.g = std::min(TRSV_MULTI_G, k0 + 1);
-            hipLaunchKernelGGL(trsv_bwd_multi_kernel, dim3(k0 + 1), dim3(256), 0, h->stream, q);
-        }
-        HIP_TRY(h, hipGetLastError());
-        return IPM_OK;
-    }
     TrsvStep a;
     a.L = h->B; a.ld = h->mp; a.inv = h->invD; a.done = &h->sc->done;
     a.r = r; a.z = h->t2;
@@ -2088,14 +2003,14 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         // stream under the chain-bound tail of the factorization
         VecArgs a = vec_args(h);
         hipLaunchKernelGGL(scaling_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
-        if (ev && !ff_ok(h)) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
+        const bool fused = ff_use(h);                        // evaluated ONCE per iteration (the live-handle count can change under it)
+        if (ev && !fused) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
         // the stop test of THIS iterate runs on the residual stream while the factorization is in flight: formation and
         // factorization test the latch scaling_kernel took (Scalars::done_f), so they either run whole or not at all and
         // after a converged solve B / invD hold the complete factor of the final iterate (ipm_get_factor, pivots_fixed)
         struct Latch { ipm_handle* h; ~Latch() { h->fdone = nullptr; } } latch{h};
         h->fdone = &h->sc->done_f;
         h->ff_last = false;
-        const bool fused = ff_ok(h);
         if (!fused) {
             if ((rc = enqueue_form(h, h->d))) return rc;
             if (ev) HIP_TRY(h, hipEventRecord(ev[2], h->stream));
@@ -2143,7 +2058,7 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
     if ((rc = enqueue_residuals(h))) return rc;
     h->ff_last = false;
     bool have_rhs = false;
-    if (ff_ok(h) && h->profiling < 2) {
+    if (h->profiling < 2 && ff_use(h)) {
         // (handles below 16 blocks have no residual stream: the fused launch is used here only when IPM_FUSED_FACTOR=force
         //  lowers the block limit -- the tests' way to run the fused kernels at small sizes)
         if ((rc = enqueue_form_factor(h, ev, -1, -1))) return rc;
@@ -2224,7 +2139,8 @@ static int read_scalars(ipm_handle* h, bool* timed_out = nullptr) {
 // call's effect on the iterate (callers restore their snapshot) and run it again.
 static void poll_fallback(ipm_handle* h) {
     if (h->spf) h->sp_serial = true;          // sparse factor: one workgroup per launch from now on (it never waits)
-    h->flag_sync = 0;
+    if (h->ff_last) h->ff_enabled = 0;        // the fused launch timed out: serial formation + factorization from now on, look-ahead kept
+    else h->flag_sync = 0;
     ++h->timeouts_recovered;
 }
 
@@ -2390,7 +2306,9 @@ extern "C" int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats) {
         bool tmo = false;
         if ((rc = read_scalars(h, &tmo))) return rc;
         if (!tmo) break;
-        if (attempt || !guard_poll) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
+        // (at most two recoveries per call: the fused launch falls back to formation + look-ahead factorization, which still polls
+        //  device counters, and that one to stream events)
+        if (attempt >= 2 || !guard_poll) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
         poll_fallback(h);
         if ((rc = enqueue_snapshot(h, 1))) return rc;
     }
@@ -2451,36 +2369,13 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     double t_enq = 0.0, t_wait = 0.0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     struct Report { const bool on; const double &a, &b; const ipm_handle* h; ~Report() { if (on) fprintf(stderr, "[ipm host] m=%lld: enqueue %.1f ms, wait %.1f ms\n", (long long)h->m, a * 1e3, b * 1e3); } } report{host_timing, t_enq, t_wait, h};
-    // Opt-in (IPM_GRAPH=1, see use_graph): single-stream handles replay a captured chunk of iterations from the third chunk
-    // on: one hipGraphLaunch instead of ~100 launches per iteration.  One stream, no events, no device polling inside the capture; every kernel still
-    // tests Scalars::done, so replaying past convergence is the same no-op as enqueueing past it.
-    struct GraphGuard { hipGraphExec_t exec = nullptr; ~GraphGuard() { if (exec) (void)hipGraphExecDestroy(exec); } } gg;
-    const bool graph_ok = h->use_graph != 0 && !h->spf && h->stream2 == nullptr && h->stream3 == nullptr && h->nblk > 1;
-    int chunk_idx = 0;
     for (;;) {
         // roll-back point: the first chunk (auto-regularize restart) and every chunk that can hit a poll time-out
         const bool snap = first || may_poll(h);
         const double t0 = host_timing ? now() : 0.0;
         if (snap && (rc = enqueue_snapshot(h, 0))) return rc;
-        if (graph_ok && !first && chunk_idx >= 2) {
-            if (!gg.exec) {
-                hipGraph_t graph = nullptr;
-                HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                int crc = IPM_OK;
-                for (int i = 0; i < chunk && !crc; ++i) crc = enqueue_iteration(h, nullptr);
-                hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-                if (crc) { if (graph) (void)hipGraphDestroy(graph); return crc; }
-                if (ce != hipSuccess) return fail(h, IPM_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-                ce = hipGraphInstantiate(&gg.exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                if (ce != hipSuccess) return fail(h, IPM_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ce));
-            }
-            HIP_TRY(h, hipGraphLaunch(gg.exec, h->stream));
-        } else {
-            for (int i = 0; i < chunk; ++i)
-                if ((rc = enqueue_iteration(h, nullptr))) return rc;
-        }
-        ++chunk_idx;
+        for (int i = 0; i < chunk; ++i)
+            if ((rc = enqueue_iteration(h, nullptr))) return rc;
         const double t1 = host_timing ? now() : 0.0;
         bool tmo = false;
         if ((rc = read_scalars(h, &tmo))) return rc;

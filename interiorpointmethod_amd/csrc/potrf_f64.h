@@ -394,9 +394,9 @@ __device__ __forceinline__ void potrf_diag_body(const PotrfDiag& a, double* W, d
             while (__hip_atomic_load(a.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.wait_count) {
                 __builtin_amdgcn_s_sleep(2);
                 ++spins;
-                if (spins > (1u << 22) || ((spins & 1023u) == 1u && a.timeout &&
+                if (spins > ipm_spin_limit || ((spins & 1023u) == 1u && a.timeout &&
                                            __hip_atomic_load(a.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (spins > (1u << 22) && a.dbg && __hip_atomic_fetch_add(a.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    if (spins > ipm_spin_limit && a.dbg && __hip_atomic_fetch_add(a.dbg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                         a.dbg[1] = a.dbg_tag; a.dbg[2] = 7u; a.dbg[3] = a.wait_count;
                         a.dbg[4] = __hip_atomic_load(a.wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -639,252 +639,6 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) {
     }
     block_gemv_t(RL, ws, us, scratch);
     if (tid < NB) a.r[(int64_t)j * NB + tid] -= us[tid];
-}
-
-// ------------------------------------------------------------------------------------------
-// Several block steps per launch WITHOUT any hand-off between workgroups (round 3): a launch covers the `g` steps k0 ..
-// k0 + g - 1 (forward) and every workgroup recomputes the g solution blocks of that group for itself -- g products with the
-// block inverses and g (g - 1) / 2 with the off-diagonal blocks of the group, 128 x 128 each, streamed through registers with the
-// next block in flight -- before it eliminates them from its own block row.  The arithmetic per block row is the one of the
-// step kernels in the same order (bitwise equal results); what is saved is g - 1 of every g dependent launches: a substitution
-// of 9 blocks is 3 launches instead of 9.  Used where the grouped inverses do not apply (block count not a multiple of the
-// group size) and no tile envelope limits the rows of a step.
-struct TrsvMulti {
-    const double* L; int64_t ld;
-    const double* inv;
-    double* r;                       // running right-hand side (consumed)
-    double* z;                       // solution
-    int k0, g;                       // forward: steps k0 .. k0+g-1; backward: steps k0, k0-1 .. k0-g+1
-    const int* done;
-};
-constexpr int TRSV_MULTI_G = 4;
-
-// The blocks a workgroup multiplies with, in order: for s = 0 .. need-1 the off-diagonal blocks (s, t), t < s, of the group and the
-// block inverse s; then, for a block row / column outside the group, its g blocks against the group.  Streamed through TWO
-// register images: the next block is in flight while the current one is multiplied (a block is 128 KB: ~1.5 us from L2).
-struct TrsvOp { int kind, s, t; };       // kind 0: off-diagonal (s, t) of the group; 1: inverse s; 2: own row/column against s; -1: end
-__device__ __forceinline__ TrsvOp trsv_next_op(TrsvOp o, int need, int g, bool outside) {
-    if (o.kind == 0) { if (o.t + 1 < o.s) return {0, o.s, o.t + 1}; return {1, o.s, 0}; }
-    if (o.kind == 1) {
-        if (o.s + 1 < need) return {0, o.s + 1, 0};
-        if (outside) return {2, 0, 0};
-        return {-1, 0, 0};
-    }
-    if (o.kind == 2 && o.s + 1 < g) return {2, o.s + 1, 0};
-    return {-1, 0, 0};
-}
-
-// grid = nblk - k0: workgroup b owns block row i = k0 + b
-__global__ __launch_bounds__(256) void trsv_fwd_multi_kernel(TrsvMulti a) {
-    if (a.done && *a.done) return;
-    __shared__ double vs[NB], us[NB], zs[TRSV_MULTI_G][NB];
-    const int tid = threadIdx.x;
-    const int i = a.k0 + (int)blockIdx.x;
-    const int mine = i - a.k0;                            // < g: this workgroup's row is solution block `mine` of the group
-    const bool outside = mine >= a.g;
-    const int need = outside ? a.g : mine + 1;            // solution blocks this workgroup has to know
-    auto block_of = [&](TrsvOp o) -> const double* {
-        if (o.kind == 0) return a.L + (int64_t)(a.k0 + o.s) * NB * a.ld + (int64_t)(a.k0 + o.t) * NB;
-        if (o.kind == 1) return a.inv + (int64_t)(a.k0 + o.s) * NB * NB;
-        return a.L + (int64_t)i * NB * a.ld + (int64_t)(a.k0 + o.s) * NB;
-    };
-    auto ld_of = [&](TrsvOp o) -> int64_t { return o.kind == 1 ? (int64_t)NB : a.ld; };
-    // v = running right-hand side of the block being solved (global -> LDS at the start and after every inverse)
-    if (tid < NB) vs[tid] = a.r[(int64_t)a.k0 * NB + tid];
-    auto apply = [&](const BlockRegs& R, TrsvOp o) {
-        if (o.kind == 1) {                                 // z_s = inv(s) v ; then v = rhs of what comes next
-            block_gemv_n(R, vs, zs[o.s]);
-            __syncthreads();
-            const int nxt = o.s + 1 < need ? a.k0 + o.s + 1 : (outside ? i : -1);
-            if (nxt >= 0 && tid < NB) vs[tid] = a.r[(int64_t)nxt * NB + tid];
-            __syncthreads();
-        } else {                                           // v -= block z_t  (kind 0: t = o.t; kind 2: t = o.s)
-            block_gemv_n(R, zs[o.kind == 0 ? o.t : o.s], us);
-            __syncthreads();
-            if (tid < NB) vs[tid] -= us[tid];
-            __syncthreads();
-        }
-    };
-    BlockRegs RA, RB;
-    TrsvOp o = {1, 0, 0};                                  // s = 0 has no off-diagonal blocks
-    block_load(RA, block_of(o), ld_of(o));
-    __syncthreads();
-    for (;;) {
-        TrsvOp o2 = trsv_next_op(o, need, a.g, outside);
-        if (o2.kind >= 0) block_load(RB, block_of(o2), ld_of(o2));
-        apply(RA, o);
-        if (o2.kind < 0) break;
-        TrsvOp o3 = trsv_next_op(o2, need, a.g, outside);
-        if (o3.kind >= 0) block_load(RA, block_of(o3), ld_of(o3));
-        apply(RB, o2);
-        if (o3.kind < 0) break;
-        o = o3;
-    }
-    if (!outside) { if (tid < NB) a.z[(int64_t)i * NB + tid] = zs[mine][tid]; }
-    else if (tid < NB) a.r[(int64_t)i * NB + tid] = vs[tid];
-}
-
-// grid = k0 + 1: workgroup b owns block column j = b; steps k0, k0 - 1 .. k0 - g + 1 (descending)
-__global__ __launch_bounds__(256) void trsv_bwd_multi_kernel(TrsvMulti a) {
-    if (a.done && *a.done) return;
-    __shared__ double vs[NB], us[NB], ws[TRSV_MULTI_G][NB];
-    __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
-    const int tid = threadIdx.x;
-    const int j = (int)blockIdx.x;
-    const int mine = a.k0 - j;                            // < g: this workgroup's column is solution block `mine` of the group
-    const bool outside = mine >= a.g;
-    const int need = outside ? a.g : mine + 1;
-    auto block_of = [&](TrsvOp o) -> const double* {       // solution block s of the group is block row / column k0 - s
-        if (o.kind == 0) return a.L + (int64_t)(a.k0 - o.t) * NB * a.ld + (int64_t)(a.k0 - o.s) * NB;     // L(k0 - t, k0 - s)^T
-        if (o.kind == 1) return a.inv + (int64_t)(a.k0 - o.s) * NB * NB;
-        return a.L + (int64_t)(a.k0 - o.s) * NB * a.ld + (int64_t)j * NB;                                   // L(k0 - s, j)^T
-    };
-    auto ld_of = [&](TrsvOp o) -> int64_t { return o.kind == 1 ? (int64_t)NB : a.ld; };
-    if (tid < NB) vs[tid] = a.r[(int64_t)a.k0 * NB + tid];
-    auto apply = [&](const BlockRegs& R, TrsvOp o) {       // (block_gemv_t ends with a barrier)
-        if (o.kind == 1) {
-            block_gemv_t(R, vs, ws[o.s], scratch);
-            const int nxt = o.s + 1 < need ? a.k0 - o.s - 1 : (outside ? j : -1);
-            if (nxt >= 0 && tid < NB) vs[tid] = a.r[(int64_t)nxt * NB + tid];
-            __syncthreads();
-        } else {
-            block_gemv_t(R, ws[o.kind == 0 ? o.t : o.s], us, scratch);
-            if (tid < NB) vs[tid] -= us[tid];
-            __syncthreads();
-        }
-    };
-    BlockRegs RA, RB;
-    TrsvOp o = {1, 0, 0};
-    block_load(RA, block_of(o), ld_of(o));
-    __syncthreads();
-    for (;;) {
-        TrsvOp o2 = trsv_next_op(o, need, a.g, outside);
-        if (o2.kind >= 0) block_load(RB, block_of(o2), ld_of(o2));
-        apply(RA, o);
-        if (o2.kind < 0) break;
-        TrsvOp o3 = trsv_next_op(o2, need, a.g, outside);
-        if (o3.kind >= 0) block_load(RA, block_of(o3), ld_of(o3));
-        apply(RB, o2);
-        if (o3.kind < 0) break;
-        o = o3;
-    }
-    if (!outside) { if (tid < NB) a.z[(int64_t)j * NB + tid] = ws[mine][tid]; }
-    else if (tid < NB) a.r[(int64_t)j * NB + tid] = vs[tid];
-}
-
-// ------------------------------------------------------------------------------------------
-// Persistent triangular solves: ONE launch per substitution instead of one per block step.
-// Workgroup i owns block row i (forward) / block column j (backward); it consumes the solution
-// blocks z_k of the earlier steps as they are published and publishes its own.  Off the critical
-// path every workgroup streams its own 128 x 128 tiles (next tile prefetched into registers while
-// it waits), so a step costs one hand-off plus two register-resident block products instead of
-// a kernel boundary plus two dependent memory latencies.
-//
-// Hand-off (placement independent, cdna guide G16 "8-byte agent atomics both sides"): the
-// producer stores z_k with relaxed agent-scope atomic stores (write-through), every storing wave
-// drains vmcnt, the workgroup barriers, then ONE lane stores the flag (relaxed, agent).  The
-// consumer polls that one word from one lane (bounded spin, s_sleep), barriers, and reads z_k
-// with relaxed agent-scope atomic loads (L1 bypass).  Flags are zeroed by a memset node before
-// every launch; epoch = 1.  Requires all nblk workgroups resident (nblk <= 256, 1 per CU) --
-// the launcher falls back to the per-step kernels otherwise.  A spin that exceeds its bound
-// sets *timeout and the workgroup gives up (results invalid, no hang).
-// ------------------------------------------------------------------------------------------
-struct TrsvPersist {
-    const double* L; int64_t ld;
-    const double* inv;
-    const double* rhs;               // input right-hand side (not modified)
-    double* z;                       // solution blocks (published through agent-scope atomics)
-    unsigned* flags;                 // [nblk], zeroed before the launch
-    unsigned* timeout;               // set to 1 when a spin gave up
-    int nblk;
-    const int* done;
-};
-
-typedef __attribute__((address_space(1))) unsigned gu32_t;
-typedef __attribute__((address_space(1))) double gf64_t;
-
-__device__ __forceinline__ bool wait_flag(unsigned* flag, unsigned* timeout) {
-    // one lane polls; returns false on timeout (wave-uniform through LDS by the caller)
-    unsigned spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22)) { __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
-    }
-    return true;
-}
-
-// forward: L z = rhs.  grid = nblk, block = 256.
-__global__ __launch_bounds__(256) void trsv_fwd_persistent_kernel(TrsvPersist a) {
-    if (a.done && *a.done) return;
-    __shared__ double acc[NB], zk[NB], us[NB];
-    __shared__ int ok_s;
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x;
-    BlockRegs RI, RA, RB;
-    block_load(RI, a.inv + (int64_t)i * NB * NB, NB);
-    if (i > 0) block_load(RA, a.L + (int64_t)i * NB * a.ld, a.ld);
-    if (tid < NB) acc[tid] = a.rhs[(int64_t)i * NB + tid];
-    if (tid == 0) ok_s = 1;
-    __syncthreads();
-    for (int k = 0; k < i; ++k) {
-        // prefetch the next tile of this block row while waiting for z_k
-        if (k + 1 < i) {
-            if (k & 1) block_load(RA, a.L + (int64_t)i * NB * a.ld + (int64_t)(k + 1) * NB, a.ld);
-            else block_load(RB, a.L + (int64_t)i * NB * a.ld + (int64_t)(k + 1) * NB, a.ld);
-        }
-        if (tid == 0 && !wait_flag(a.flags + k, a.timeout)) ok_s = 0;
-        __syncthreads();
-        if (!ok_s) return;
-        if (tid < NB) zk[tid] = __hip_atomic_load(a.z + (int64_t)k * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (k & 1) block_gemv_n(RB, zk, us); else block_gemv_n(RA, zk, us);
-        __syncthreads();
-        if (tid < NB) acc[tid] -= us[tid];
-        __syncthreads();
-    }
-    block_gemv_n(RI, acc, us);
-    __syncthreads();
-    if (tid < NB) __hip_atomic_store(a.z + (int64_t)i * NB + tid, us[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(a.flags + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// backward: L^T w = rhs.  Workgroup b owns block column j = nblk-1-b (so the first-dispatched
-// workgroups are the first on the dependency chain).
-__global__ __launch_bounds__(256) void trsv_bwd_persistent_kernel(TrsvPersist a) {
-    if (a.done && *a.done) return;
-    __shared__ double acc[NB], wk[NB], us[NB];
-    __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
-    __shared__ int ok_s;
-    const int tid = threadIdx.x;
-    const int j = a.nblk - 1 - (int)blockIdx.x;
-    BlockRegs RI, RA, RB;
-    block_load(RI, a.inv + (int64_t)j * NB * NB, NB);
-    const int last = a.nblk - 1;
-    if (j < last) block_load(RA, a.L + (int64_t)last * NB * a.ld + (int64_t)j * NB, a.ld);
-    if (tid < NB) acc[tid] = __hip_atomic_load(a.rhs + (int64_t)j * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid == 0) ok_s = 1;
-    __syncthreads();
-    for (int k = last, it = 0; k > j; --k, ++it) {
-        if (k - 1 > j) {
-            if (it & 1) block_load(RA, a.L + (int64_t)(k - 1) * NB * a.ld + (int64_t)j * NB, a.ld);
-            else block_load(RB, a.L + (int64_t)(k - 1) * NB * a.ld + (int64_t)j * NB, a.ld);
-        }
-        if (tid == 0 && !wait_flag(a.flags + k, a.timeout)) ok_s = 0;
-        __syncthreads();
-        if (!ok_s) return;
-        if (tid < NB) wk[tid] = __hip_atomic_load(a.z + (int64_t)k * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (it & 1) block_gemv_t(RB, wk, us, scratch); else block_gemv_t(RA, wk, us, scratch);
-        if (tid < NB) acc[tid] -= us[tid];
-        __syncthreads();
-    }
-    block_gemv_t(RI, acc, us, scratch);
-    if (tid < NB) __hip_atomic_store(a.z + (int64_t)j * NB + tid, us[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(a.flags + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ipm

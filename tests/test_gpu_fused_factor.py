@@ -90,9 +90,9 @@ def test_fused_path_factor_of_a_given_scaling(monkeypatch):
 
 
 def test_default_rule_selects_the_fused_path_where_it_was_measured_faster():
-    """The selection rule (ipm_api.hip: from 20 blocks on, up to 40, n <= 3 m): the headline size runs fused, a wide LP
-    (formation-dominated) and a small one do not."""
-    for (m, n), want in (((4096, 8192), 1), ((2048, 4096), 0), ((2560, 10240), 0)):
+    """The selection rule (ipm_api.hip: 16 .. 72 blocks, n <= 6 m; profiles/r04_ff_sizes_fused_vs_serial.txt): the headline size and
+    a 16-block LP run fused, a very wide LP (formation-dominated) and a small one do not."""
+    for (m, n), want in (((4096, 8192), 1), ((2048, 4096), 1), ((1536, 3072), 0), ((2048, 16384), 0)):
         A, b, c = synthetic_lp(m, n, seed=1)
         with ipm.IpmSolver(A, b, c) as sv:
             sv.init_state(0.0)

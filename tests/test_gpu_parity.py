@@ -867,14 +867,21 @@ def _check_lp_properties(A, b, c, st, x, y, s):
 
 
 def test_dense_6200x9000_default_two_level(monkeypatch):
-    """49 blocks: the size from which the two-level Cholesky (groups of 3) is the DEFAULT schedule.  Same
+    """49 blocks: the size from which the two-level Cholesky (groups of 3) is the schedule of the SERIAL path (formation, then
+    factorization; since round 4 the default at this size is the fused launch, which this test also runs and compares).  Same
     iteration count and objective as the one-level factor (IPM_TWO_LEVEL=0) and the LP-level properties.  49 is no multiple
     of the 8-block groups of the triangular solves: six full groups get their explicit inverses, the last block is solved as
     a block step (ragged groups, round 3) -- same answer as the block-step substitutions alone (IPM_RAGGED_GROUPS=0)."""
     A, b, c = synthetic_lp(6200, 9000, seed=2)
+    stf, xf, yf, sf, schedf = _solve_checked(A, b, c)
+    assert schedf["blocks"] == 49 and schedf["fused_factor"] == 1 and schedf["timeouts_recovered"] == 0
+    _check_lp_properties(A, b, c, stf, xf, yf, sf)
+    monkeypatch.setenv("IPM_FUSED_FACTOR", "0")
     st, x, y, s, sched = _solve_checked(A, b, c)
-    assert sched["blocks"] == 49 and sched["group_steps"] == 3 and sched["grouped_trsv"] == 1
+    assert sched["blocks"] == 49 and sched["group_steps"] == 3 and sched["grouped_trsv"] == 1 and sched["fused_factor"] == 0
     _check_lp_properties(A, b, c, st, x, y, s)
+    assert stf["iterations"] == st["iterations"] and abs(stf["objective"] - st["objective"]) <= 1e-9 * max(1.0, abs(st["objective"]))
+    assert rel(xf, x) < 1e-6
     monkeypatch.setenv("IPM_TWO_LEVEL", "0")
     st1, x1, _, _, sched1 = _solve_checked(A, b, c)
     assert sched1["group_steps"] == 1 and st1["iterations"] == st["iterations"]

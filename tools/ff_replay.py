@@ -12,14 +12,26 @@ INIT, ADD_BASE, PANEL, SIG0 = 1, 2, 4, 8
 
 
 class Model:
+    """chain_mode 0 (three launches per chain step beside 224 workers), calibrated on profiles/r04_ff_item_trace_baseline.txt"""
     f_over, f_stage = 17.9, 3.91          # F chunk: us fixed + per BK=16 stage
-    t_over, t_col, t_base, t_panel, t_rmw = 4.1, 15.8, 53.0, 21.0, 2.0
+    t_over, t_col, t_base, t_panel, t_rmw = 4.1, 15.8, 53.0, 21.0, 2.0     # t_base: FOUR slabs
     gap = 0.8                             # end of an item -> next ticket drawn
     d_item = 140.0
     potrf, cpanel, cupdate = 36.0, 8.0, 5.0
     g_potrf_panel, g_panel_update, g_update_potrf = 3.5, 3.5, 4.0
     chain_start = 220.0                   # ff_maxdiag in front of potrf(0)
     handoff = 1.5                         # counter visible to a spinning consumer
+
+
+class ModelRoles(Model):
+    """chain_mode 1 (the chain as roles of the one launch, 251 workers), calibrated on profiles/r04_ff_item_trace_roles_kernel.txt"""
+    f_over, f_stage = 6.1, 4.02
+    t_over, t_col, t_base, t_panel, t_rmw = 7.0, 15.9, 27.0, 18.3, 1.0
+    d_item = 397.0
+    potrf, cpanel, cupdate = 36.8, 7.3, 7.3
+    g_potrf_panel, g_panel_update, g_update_potrf = 1.0, 1.5, 1.0
+    chain_start = 0.0
+    handoff = 1.0
 
 
 def tile_id(i, c):

@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from interiorpointmethod_amd import _lib          # noqa: E402
-from tools.ff_replay import replay, summary       # noqa: E402
+from tools.ff_replay import replay, summary, Model, ModelRoles       # noqa: E402
 
 
 def schedule(nblk=32, q=4, workers=224):
@@ -35,9 +35,12 @@ if __name__ == "__main__":
     for combo in itertools.product(*[knobs[k] for k in keys]):
         for k, v in zip(keys, combo):
             os.environ["IPM_FF_" + k] = v
-        items, sim = schedule()
+        mode = int(os.environ.get("IPM_FF_CHAIN_MODE", "1"))
+        os.environ["IPM_FF_CHAIN_MODE"] = str(mode)
+        W = 251 if mode else 224
+        items, sim = schedule(workers=W)
         try:
-            r = replay(items, 32)
-            print(" ".join("%s=%s" % kv for kv in zip(keys, combo)), "| items %d | generator's own sim %.0f | replay: %s" % (len(items), sim[0], summary(r)))
+            r = replay(items, 32, W=W, M=ModelRoles if mode else Model, mode=mode)
+            print(" ".join("%s=%s" % kv for kv in zip(keys, combo)), "| items %d | generator's own sim %.0f | replay: %s" % (len(items), sim[0], summary(r, W)))
         except RuntimeError as e:
             print(" ".join("%s=%s" % kv for kv in zip(keys, combo)), "| replay failed:", e)

@@ -49,7 +49,7 @@ def kernel_source_sha(fused=False):
     (profiles/*_pmc_form_kernel*.json carries the kernel name and the sha it was collected with)."""
     import hashlib
     hsh = hashlib.sha256()
-    for f in ("adat_syrk_f64.h", "gemm_nt_f64.h") + (("form_factor.h", "ff_schedule.h") if fused else ()):
+    for f in ("adat_syrk_f64.h", "gemm_nt_f64.h") + (("form_factor.h", "ff_schedule.h", "potrf_f64.h") if fused else ()):
         with open(os.path.join(ROOT, "interiorpointmethod_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]
@@ -583,10 +583,15 @@ def main():
         its_per_s = ngpu * K / elapsed
         form_ms = phases[0] / K
         nblk = (m + 127) // 128
-        if fused:
-            # the dominant kernel is the persistent worker launch: the formation (m^2 n) AND the factorization's matrix work
-            # outside the pivot chain (m^3 / 3 minus, per 128-row block, the diagonal block's own factorization and the chain's
-            # panel solve and tile update: 128^3 (1/3 + 2 + 1) flop)
+        roles = fused and os.environ.get("IPM_FF_CHAIN_MODE", "1") != "0"
+        if roles:
+            # the dominant kernel is the ONE persistent launch that forms B = A D^2 A^T (m^2 n) and factors it (m^3 / 3): the pivot
+            # chain and its small products are roles of the same launch
+            flops_form = float(m) * m * n + float(m) ** 3 / 3.0
+        elif fused:
+            # chain_mode 0: the worker launch does the formation (m^2 n) AND the factorization's matrix work outside the pivot chain
+            # (m^3 / 3 minus, per 128-row block, the diagonal block's own factorization and the chain's panel solve and tile
+            # update: 128^3 (1/3 + 2 + 1) flop)
             flops_form = float(m) * m * n + float(m) ** 3 / 3.0 - nblk * 128.0 ** 3 * (1.0 / 3.0 + 3.0)
         else:
             flops_form = float(m) * m * n                       # lower-triangle SYRK, SURVEY 8(d)
@@ -608,7 +613,10 @@ def main():
                                          "the committed PMC pass was collected for another kernel source or size; algorithmic "
                                          "bytes 8mn + 4m^2 (+ 4m^2 for L when the launch also factors)",
                          "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m * (2.0 if fused else 1.0),
-                         "kernel": ("form_factor_kernel (persistent launch beside the pivot chain: B = A diag(d) A^T in 256x128 tile pairs + every "
+                         "kernel": ("form_factor_roles_kernel (ONE persistent launch of as many workgroups as CUs: B = A diag(d) A^T in 256x128 tile "
+                                    "pairs, every update and panel solve of its Cholesky, and the pivot chain as roles of the launch; "
+                                    "v_mfma_f64_16x16x4_f64)" if roles else
+                                    "form_factor_kernel (persistent launch beside the pivot chain: B = A diag(d) A^T in 256x128 tile pairs + every "
                                     "trailing update and panel solve of the Cholesky outside the chain, v_mfma_f64_16x16x4_f64; 224 of 256 CUs)"
                                     if fused else "adat_syrk_kernel (B = A diag(d) A^T, lower 128x128 tiles, v_mfma_f64_16x16x4_f64)"),
                          "fused_formation_and_factorization": fused,

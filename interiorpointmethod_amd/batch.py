@@ -97,7 +97,9 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
 
 def _in_own_stream(solve_fn, problem, device, kw):
     """Run solve_fn with a torch stream of its own as the thread's current stream (a handle binds to the current
-    stream), so solves issued from different host threads overlap on the GPU."""
+    stream), so solves issued from different host threads overlap on the GPU.  (High-priority streams for the largest LPs
+    were measured in round 4 and make the suite SLOWER: 14.5 LPs/s without, 13.0 / 13.3 / 11.2 with the LPs of >= 1000 /
+    2000 / 3000 rows prioritised -- profiles/r04_netlib_stream_priority_rejected.txt.)"""
     try:
         import torch
         if torch.cuda.is_available():

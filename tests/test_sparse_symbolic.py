@@ -190,7 +190,11 @@ def _numpy_etree_and_counts(P):
     return parent, counts
 
 
-@pytest.mark.parametrize("name", ["AFIRO", "SC205", "BANDM", "SCTAP1"])
+# the ten LPs the `factor="auto"` rule routes to the sparse factor (80BAU3B ... STOCFOR3: DESIGN 4-S), after four small ones
+SPARSE_PATH_LPS = ["80BAU3B", "CZPROB", "GANGES", "GFRD-PNC", "SCTAP2", "SCTAP3", "SHELL", "SIERRA", "STOCFOR2", "STOCFOR3"]
+
+
+@pytest.mark.parametrize("name", ["AFIRO", "SC205", "BANDM", "SCTAP1"] + SPARSE_PATH_LPS)
 def test_etree_and_column_counts_against_an_independent_numpy_restatement(oracle, name):
     """The product's symbolic analysis (order -> elimination tree -> column structures by child merging -> panels) against
     a NumPy restatement that shares nothing with csrc/sparse_symbolic.h: same elimination-tree parent array, same number

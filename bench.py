@@ -286,11 +286,10 @@ def load_netlib(which, max_m=1 << 30):
         # none --; the four triangular sweeps (4 nnz(L) or 4 m^2); 12 nnz for the six SpMVs
         A = sparse.csc_matrix(A)
         names.append(nm); probs.append((A, b, c))
-        path, f_chol, f_sweeps = path_flops(A)
+        path, f_chol, f_sweeps, info = path_flops(A, want_info=True)
         PATHS[nm] = path
         if path == "sparse":
-            from interiorpointmethod_amd import solver as _S
-            ORDER_INFO[nm] = _S.ORDER_INFO_CACHE.pop(id(A), None)
+            ORDER_INFO[nm] = info
         flops.append(float(np.sum(np.diff(A.indptr).astype(np.float64) ** 2)) + f_chol + f_sweeps + 12.0 * A.nnz)
 
     if which == "general":

@@ -256,6 +256,9 @@ int ipm_debug_get_stamps(ipm_handle* h, long long* out);
 int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, unsigned char* items, int32_t capacity, int32_t* count,
                           int32_t* tile_items, double sim_us[2]);
 int ipm_get_phase_ms(ipm_handle* h, double out[4]);
+/* Test hook: inv(L_kk) of diagonal block k of the handle's current dense factor, 128 x 128 row-major (zeros above the diagonal), to
+ * host `out`.  Rows of the block beyond the LP's row count are padding: the identity (tests/test_gpu_parity.py). */
+int ipm_debug_get_block_inverse(ipm_handle* h, int32_t k, double* out);
 /* Diagnostic (environment IPM_FF_TRACE_ITEMS=1 at ipm_create; IPM_ERR_STATE otherwise): time line of the LAST fused formation +
  * factorization launch on the device-wide 100 MHz clock.  *count = words of the trace: 4 per work item {drawn, inputs ready,
  * done, worker} followed by 12 per 128-row block {potrf_diag: start, inputs ready, done, -; critical panel: same; critical

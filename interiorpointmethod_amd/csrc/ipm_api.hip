@@ -1778,6 +1778,15 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     return IPM_OK;
 }
 
+extern "C" int ipm_debug_get_block_inverse(ipm_handle* h, int32_t k, double* out) {
+    if (!h || !out || k < 0 || k >= h->nblk) return fail(h, IPM_ERR_INVALID_ARG, "ipm_debug_get_block_inverse: bad arguments");
+    if (!h->invD) return fail(h, IPM_ERR_STATE, "the handle holds no dense factor");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(out, h->invD + (int64_t)k * NB * NB, sizeof(double) * NB * NB, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return IPM_OK;
+}
+
 extern "C" int ipm_debug_ff_trace(ipm_handle* h, long long* out, int64_t capacity, int64_t* count, unsigned char* items, int32_t* nitems) {
     if (!h || !count) return fail(h, IPM_ERR_INVALID_ARG, "ipm_debug_ff_trace: bad arguments");
     if (!h->ff_trace || !h->ff_built) return fail(h, IPM_ERR_STATE, "no item trace (IPM_FF_TRACE_ITEMS=1 at ipm_create, fused path)");

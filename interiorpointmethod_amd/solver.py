@@ -94,7 +94,6 @@ def sparse_factor_order(A, alternative_ms=0.0):
 
 SPARSE_FACTOR_MIN_ROWS = 600          # below five 128-row blocks the dense chain is shorter than one tree sweep set
 FUSED_SMALL_MAX_ROWS = 128            # sparse handles up to this many rows run the fused single-workgroup kernel (small_lp.h)
-ORDER_INFO_CACHE = {}                 # id(A) -> ipm_order_rows info of the LPs path_flops put on the sparse factor (bench.py)
 
 
 def prefer_sparse_factor(m, info, dense_blocks):
@@ -126,19 +125,21 @@ def _worth_ordering(A):
     return float(np.sum(c * (c - 1.0) / 2.0)) <= 4.0e6
 
 
-def path_flops(A, factor=None):
+def path_flops(A, factor=None, want_info=False):
     """(path, Cholesky flops, flops of the four triangular sweeps) of one iteration AS THE DEVICE RUNS IT for this A under
     IpmSolver's factor rule: the sparse factor costs sum over columns of (entries of the column)^2 and 4 nnz(L); the
-    dense-tile path factor_flops(A) and 4 m^2.  bench.py's roofline denominator for the Netlib runs."""
+    dense-tile path factor_flops(A) and 4 m^2.  bench.py's roofline denominator for the Netlib runs.
+    want_info: a fourth value, the ipm_order_rows info of an LP put on the sparse factor (None otherwise)."""
     m = A.shape[0]
     factor = factor or os.environ.get("IPM_FACTOR", "auto")
     if _sp is not None and _sp.issparse(A) and factor != "dense" and m > FUSED_SMALL_MAX_ROWS and \
             (factor == "sparse" or (m >= SPARSE_FACTOR_MIN_ROWS and _worth_ordering(_sp.csc_matrix(A)))):
         perm, info = sparse_factor_order(A, 0.0 if factor == "sparse" else dense_tile_ms((m + 127) // 128))
         if perm is not None and (factor == "sparse" or prefer_sparse_factor(m, info, (m + 127) // 128)):
-            ORDER_INFO_CACHE[id(A)] = info
-            return "sparse", float(info["flops"]), 4.0 * info["nnz_factor"]
-    return "dense", factor_flops(A), 4.0 * m * m
+            out = ("sparse", float(info["flops"]), 4.0 * info["nnz_factor"])
+            return out + (info,) if want_info else out
+    out = ("dense", factor_flops(A), 4.0 * m * m)
+    return out + (None,) if want_info else out
 
 
 def factor_flops(A, nb=128):

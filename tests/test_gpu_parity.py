@@ -1069,3 +1069,30 @@ def test_plain_c_driver():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("fused", ["0", "force"])
+def test_padding_rows_of_the_block_inverses_are_the_identity(monkeypatch, fused):
+    """potrf_diag factors only the 16-wide panels of a partial last block that hold rows of the LP and FILLS the
+    inverse of the padding rows with the identity; the fill raced with the block load in LDS (fixed with a barrier in round 4).
+    m = 1100 = 8 x 128 + 76: the last block has 5 factored panels (80 rows), rows 80 .. 127 of inv(L_88) must be EXACTLY e_i, rows
+    76 .. 79 (padding inside the last factored panel: unit diagonal of B) as well, on the serial chain and on the fused launch; and
+    the inverse of the real part inverts L (1e-12)."""
+    import ctypes as C
+    from interiorpointmethod_amd import _lib
+    m, n = 1100, 2300
+    A, b, c = synthetic_lp(m, n, seed=7)
+    monkeypatch.setenv("IPM_FUSED_FACTOR", fused)
+    with ipm.IpmSolver(A, b, c) as sv:
+        sv.init_state(0.0)
+        sv.iterate(2)
+        assert sv.schedule()["fused_factor"] == (1 if fused == "force" else 0)
+        L = sv.get_factor()
+        inv = np.zeros((128, 128))
+        sv._check(_lib.load().ipm_debug_get_block_inverse(sv._h, 8, inv.ctypes.data_as(C.POINTER(C.c_double))))
+    real = m - 8 * 128
+    assert np.array_equal(inv[real:, :], np.eye(128)[real:, :])                       # exact unit rows on the padding
+    assert np.array_equal(inv[:, real:], np.eye(128)[:, real:])
+    L88 = L[8 * 128:, 8 * 128:]
+    assert np.max(np.abs(inv[:real, :real] @ L88 - np.eye(real))) < 1e-12
+    assert np.all(np.triu(inv, 1) == 0.0)

@@ -54,9 +54,6 @@ struct ipm_handle {
     hipStream_t stream2 = nullptr;            // bulk stream of the Cholesky look-ahead
     hipStream_t stream3 = nullptr;            // residual stream: r_b, r_c, stop test and the predictor rhs under the factorization
     hipEvent_t ev_mid = nullptr, ev_res = nullptr, ev_grp = nullptr, ev_last = nullptr;
-    int overlap_ginv = 1;                     // all 1024-row group inverses but the last one under the tail of the factorization (IPM_OVERLAP_GINV)
-    int overlap_res = 1;                      // IPM_OVERLAP_RESIDUALS=0: residuals before the formation (round-1 order)
-    int residual_step = -1;                   // factorization step at which the residual stream starts (-1: 13/16 nblk; IPM_RESIDUAL_STEP)
     std::vector<hipEvent_t> ev_diag, ev_crit, ev_bulk;
     hipEvent_t ev_fork = nullptr;
     int lookahead = 1;
@@ -105,7 +102,6 @@ struct ipm_handle {
                                           // launch per sweep even when the device is shared; 0: sp_level() decides
     std::vector<int> sp_lvlptr;           // [levels + 1] into the level-ordered records
     SpRec* sp_rec_level = nullptr;
-    bool sp_sc1 = false;                  // IPM_SP_SC1=1: write-through stores + sc1 loads instead of the release / acquire fence pair
     unsigned sp_epoch = 0;
     double shift_rel = 0.0;               // Tikhonov shift in effect (opt.regularize, or 1e-14 switched on by ipm_solve)
     int auto_reg = 0;                     // 1: the shift was switched on automatically
@@ -122,7 +118,6 @@ struct ipm_handle {
     double *dxa = nullptr, *dsa = nullptr, *dx = nullptr, *ds = nullptr;
     double *y = nullptr, *b = nullptr, *rb = nullptr, *t1 = nullptr, *t2 = nullptr, *dya = nullptr, *dy = nullptr;
     double *atp = nullptr, *part = nullptr, *slab = nullptr;
-    int form_variant = 0;
     // fused formation + factorization (form_factor.h): dense handles of FF_MIN_NBLK .. FF_MAX_NBLK blocks that have the device to
     // themselves run ONE persistent worker launch beside the pivot chain instead of formation followed by factorization
     int ff_enabled = 1;                   // IPM_FUSED_FACTOR=0 disables, =force also below FF_MIN_NBLK blocks (tests)
@@ -200,7 +195,7 @@ static inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * 
 // Device memory the handle owns besides its workspace.  STREAM-ORDERED (hipMallocAsync / hipFreeAsync on the handle's
 // stream, pool kept for reuse): a plain hipFree synchronises the whole device, and with several LPs in flight every one
 // of a handle's ~30 frees waited for the other LPs' queued iterations -- measured in the 73-LP suite: STOCFOR3 0.46 s of
-// solve and 1.14 s of teardown, SIERRA 0.12 s and 1.19 s.  IPM_ASYNC_ALLOC=0 restores hipMalloc / hipFree.
+// solve and 1.14 s of teardown, SIERRA 0.12 s and 1.19 s.
 static std::atomic<int> g_pool_state[64];       // per device: 0 unknown, 1 stream-ordered allocation available, 2 not
 static hipMemPool_t g_pool[64];                 // the library's OWN pool per device (never the device's default pool: its
                                                 // attributes belong to the host application)
@@ -213,8 +208,7 @@ static bool async_alloc_ok(int device) {
         st = g_pool_state[device].load(std::memory_order_acquire);
         if (st != 0) return st == 1;
         int supported = 0;
-        const char* e = getenv("IPM_ASYNC_ALLOC");
-        if (!(e && atoi(e) == 0) && hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported) {
+        if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported) {
             hipMemPoolProps props;
             memset(&props, 0, sizeof props);
             props.allocType = hipMemAllocationTypePinned;
@@ -227,7 +221,6 @@ static bool async_alloc_ok(int device) {
                 // one LP is ~20 blocks); beyond it they go back to the device at the next synchronisation point instead of
                 // staying resident for the life of the process
                 uint64_t keep = (uint64_t)2 << 30;
-                if (const char* k = getenv("IPM_POOL_KEEP_MB")) keep = (uint64_t)atoll(k) << 20;
                 (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
                 g_pool[device] = pool;
                 st = 1;
@@ -450,7 +443,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     h->d_rowptr = (int*)(base + L.off_rowptr); h->d_colptr = (int*)(base + L.off_colptr);
     h->d_colind = (int*)(base + L.off_colind); h->d_rowind = (int*)(base + L.off_rowind);
     h->d_rval = (double*)(base + L.off_rval); h->d_cval = (double*)(base + L.off_cval);
-    if (const char* e = getenv("IPM_FORM_VARIANT")) h->form_variant = atoi(e);
     {   // test knob (see gemm_nt_f64.h): spin bound of the device-side hand-offs; set in every case, so that a later handle restores the default
         unsigned lim = 1u << 22;
         if (const char* e = getenv("IPM_TEST_SPIN_LIMIT")) lim = (unsigned)std::max(1, atoi(e));
@@ -484,7 +476,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
             for (int p2 = GS_MAX; p2 >= 2; p2 /= 2) if (h->nblk % p2 == 0) { h->gsz = p2; break; }
             if (ragged && h->nblk > GS_MAX && h->gsz < 4) h->gsz = GS_MAX;
         }
-        if (const char* e = getenv("IPM_GROUP_BLOCKS")) { const int v = atoi(e); if (v >= 2 && v <= GS_MAX && (v & (v - 1)) == 0 && h->nblk % v == 0) h->gsz = v; }
     }
     if (h->gsz > 0) {
         const size_t nG = (size_t)h->nblk / h->gsz, GR = (size_t)h->gsz * 128;
@@ -506,7 +497,6 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (const char* e = getenv("IPM_FLAG_SYNC")) h->flag_sync = atoi(e);
     if (h->opt.flags & IPM_FLAG_NO_DEVICE_POLLING) h->flag_sync = 0;
     if (const char* e = getenv("IPM_BULK_VARIANT")) h->bulk_variant = atoi(e);
-    if (const char* e = getenv("IPM_SS_SMALL_TILES")) h->ss_small_blocks = atoi(e);
     if (const char* e = getenv("IPM_TWO_LEVEL")) h->two_level = atoi(e);
     if (const char* e = getenv("IPM_GROUP_STEPS")) h->group_steps = atoi(e);
     if (const char* e = getenv("IPM_FUSED_SMALL")) h->fused_small = atoi(e);
@@ -515,24 +505,20 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->lookahead != 0 && h->nblk > 2)                  // (a single-stream handle creates no second stream: see stream3 below)
         CREATE_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    if (const char* e = getenv("IPM_OVERLAP_RESIDUALS")) h->overlap_res = atoi(e);
     // The residual stream exists only where it is used (dense handles from 16 blocks on): the HIP runtime maps streams onto a
     // handful of hardware queues in creation order, and an idle third stream per handle pushes the streams of the NEXT handle
     // onto queues that this handle's chain already occupies (two concurrent solves then serialise: tools/concurrency_probe.py)
-    if (h->overlap_res && !h->sparse && h->lookahead != 0 && h->nblk >= 16)
+    if (!h->sparse && h->lookahead != 0 && h->nblk >= 16)
         CREATE_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_res, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_grp, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming));
-    if (const char* e = getenv("IPM_OVERLAP_GINV")) h->overlap_ginv = atoi(e);
     if (const char* e = getenv("IPM_FUSED_FACTOR")) { if (!strcmp(e, "force")) { h->ff_enabled = 1; h->ff_min_nblk = 3; h->ff_forced = true; } else h->ff_enabled = atoi(e); }
     if (const char* e = getenv("IPM_FF_MAX_NBLK")) h->ff_max_nblk = atoi(e);
     if (const char* e = getenv("IPM_FF_CHAIN_MODE")) h->ff_chain_mode = atoi(e) != 0;
     if (const char* e = getenv("IPM_FF_Q")) h->ff_q = std::max(1, std::min(16, atoi(e)));
-    if (const char* e = getenv("IPM_FF_WORKERS")) h->ff_workers = std::max(1, atoi(e));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_ffjoin, hipEventDisableTiming));
-    if (const char* e = getenv("IPM_RESIDUAL_STEP")) h->residual_step = atoi(e);
     h->ev_diag.assign(h->nblk, nullptr); h->ev_crit.assign(h->nblk, nullptr); h->ev_bulk.assign(h->nblk, nullptr);
     for (int k = 0; k < h->nblk; ++k) {
         CREATE_TRY(hipEventCreateWithFlags(&h->ev_diag[k], hipEventDisableTiming));
@@ -668,7 +654,6 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     const int m = (int)h->m, n = (int)h->n;
     sym::Supernodes S;
     double relax = 1.0;
-    if (const char* e = getenv("IPM_SP_RELAX")) relax = atof(e);
     if (!sym_cache_take(m, n, cp, ri, relax, S)) {          // not ordered through ipm_order_rows just before: analyse here
         sym::Pattern P;
         if (!sym::normal_pattern(m, n, cp.data(), ri.data(), (int64_t)1.5e8, P))
@@ -692,9 +677,8 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     //  off the critical path -- measured: 2048 workgroups drawing 3000 tasks spend 0.2 ms per sweep on the counter alone)
     // one-wave workgroups (four times the panels in flight) are an option, not the default: measured 35 % SLOWER at STOCFOR3
     // (fronts of <= 56 rows): a panel is instruction-latency bound and 256 threads share its loops
-    const int threads = (getenv("IPM_SP_THREADS") && atoi(getenv("IPM_SP_THREADS")) == 64) ? 64 : SPC_THREADS;
-    double div = threads == 64 ? 3072.0 : 1536.0;
-    if (const char* e = getenv("IPM_SP_TASK_DIV")) div = std::max(1.0, atof(e));
+    const int threads = SPC_THREADS;      // (one-wave workgroups, four times the panels in flight, were measured 35 % slower at STOCFOR3)
+    double div = 1536.0;
     const double T = std::max(8.0, total / div);
     std::vector<int> taskof((size_t)nsn, -1), topkids((size_t)nsn, 0);
     for (int J = 0; J < nsn; ++J) if (sub[J] > T && S.parent[J] >= 0) topkids[S.parent[J]]++;
@@ -835,7 +819,6 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->sp_nslot = nslot; h->sp_nu = S.uptr[nsn]; h->sp_height = S.height; h->sp_rmax = S.rmax; h->sp_nvirtual = S.nvirtual;
     h->sp_lds_doubles = (int)std::max<int64_t>(std::max<int64_t>(16, S.panel_max), std::min<int64_t>((int64_t)S.rmax * S.rmax, SPC_FRONT));
-    if (const char* e = getenv("IPM_SP_FRONT")) h->sp_lds_doubles = (int)std::max<int64_t>(std::max<int64_t>(16, S.panel_max), std::min<int64_t>((int64_t)S.rmax * S.rmax, atoi(e)));
     {   // LDS of the factorization kernel: the largest panel image with its padded row stride (sparse_chol.h: sp_chol_lds_need)
         long long need = 16;
         for (int J = 0; J < nsn; ++J) need = std::max(need, sp_chol_lds_need((int)(S.rowptr[(size_t)J + 1] - S.rowptr[(size_t)J]), S.w[(size_t)J], h->sp_lds_doubles));
@@ -849,19 +832,12 @@ static int build_sparse_factor(ipm_handle* h, const std::vector<int>& cp, const 
         // fronts beyond ~5000 rows: the forward sweep's update vector + diagonal block pass the default dynamic-LDS limit
         const int cap = 96 * 1024;
         if (h->sp_lds_solve > (size_t)cap || h->sp_lds_chol > (size_t)cap) return fail(h, IPM_ERR_INVALID_ARG, "sparse factor: a front of %d rows exceeds the LDS budget of the sweeps", S.rmax);
-        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<SPC_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         HIP_TRY(h, hipFuncSetAttribute((const void*)sp_fwd_kernel<SPC_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<SPC_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         HIP_TRY(h, hipFuncSetAttribute((const void*)sp_chol_kernel<SPC_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     }
     // Fence-free hand-off (write-through stores + sc1 loads) is OPT-IN (IPM_SP_SC1=1): it passes every test and is 8-12 % faster
     // per sweep at STOCFOR3 (0.358 / 0.182 / 0.141 -> 0.328 / 0.161 / 0.132 ms), but this kernel runs several workgroups per CU,
     // outside the configurations that form is documented for; the release / acquire pair is the default.
-    h->sp_sc1 = getenv("IPM_SP_SC1") && atoi(getenv("IPM_SP_SC1")) != 0;
     {   // workgroups the chip holds at once: LDS- or wave-limited (32 waves per CU)
         const size_t lds = std::max(h->sp_lds_chol, h->sp_lds_solve) + 512;
         const int wave_cap = threads == 64 ? 16 : 8;
@@ -909,8 +885,7 @@ extern "C" int ipm_order_rows(int64_t m, int64_t n, const int32_t* colptr, const
         // needs.  Kept for that call (sym_cache): the caller permutes the rows and hands the matrix over next.
         sym::Supernodes S;
         double relax = 1.0;
-        if (const char* e = getenv("IPM_SP_RELAX")) relax = atof(e);
-        if ((int64_t)P.idx.size() <= (int64_t)1.5e8 && sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax) == 0) {
+            if ((int64_t)P.idx.size() <= (int64_t)1.5e8 && sym::analyse(P, SPC_WCAP, SPC_PANEL, S, (int64_t)2.5e8, relax) == 0) {
             double area = 0.0; int levels = 0;
             sym::critical_path(S, area, levels);
             info[4] = (double)S.height; info[5] = area; info[6] = (double)S.nsn; info[7] = (double)S.rmax;
@@ -1305,12 +1280,9 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
     g.P = h->A; g.ldp = h->np; g.Q = h->A; g.ldq = h->np; g.w = d;
     g.C = h->B; g.ldc = h->mp; g.M = (int)h->mp; g.N = (int)h->mp; g.K = (int)h->np;
     g.alpha = 1.0; g.beta = 0.0; g.lower = 1; g.unit_diag_from = (int)h->m; g.done = h->fdone ? h->fdone : &h->sc->done;
-    if (h->form_variant == 0 && h->np <= (1 << 20)) {      // dedicated software-pipelined kernel (adat_syrk_f64.h)
-        HIP_TRY(h, launch_adat_syrk(h->A, h->np, d, h->B, h->mp, (int)h->mp, (int)h->np, (int)h->m, h->fdone ? h->fdone : &h->sc->done,
-                                    h->d_tile_order, h->stream, h->slab, 512));
-        return IPM_OK;
-    }
-    HIP_TRY(h, (launch_gemm_nt<128, 128, 16, 2, 2>(g, h->stream, h->slab, 512)));      // IPM_FORM_VARIANT=7: the generic kernel (round 1; bit-identical, tested)
+    // the dedicated software-pipelined kernel (adat_syrk_f64.h; the generic gemm_nt kernel it replaced in round 2 computes the same bits)
+    HIP_TRY(h, launch_adat_syrk(h->A, h->np, d, h->B, h->mp, (int)h->mp, (int)h->np, (int)h->m, h->fdone ? h->fdone : &h->sc->done,
+                                h->d_tile_order, h->stream, h->slab, 512));
     return IPM_OK;
 }
 
@@ -1339,8 +1311,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
                        sp_fwd_rhs, h->t2, h->sp_fv_off)
 #define SP_CHOL(GRID, RECS, COUNT)                                                                                                   \
     do {                                                                                                                             \
-        if (h->sp_threads == 64) { if (h->sp_sc1) SP_LAUNCH_CHOL(64, true, GRID, RECS, COUNT); else SP_LAUNCH_CHOL(64, false, GRID, RECS, COUNT); } \
-        else { if (h->sp_sc1) SP_LAUNCH_CHOL(SPC_THREADS, true, GRID, RECS, COUNT); else SP_LAUNCH_CHOL(SPC_THREADS, false, GRID, RECS, COUNT); } \
+        SP_LAUNCH_CHOL(SPC_THREADS, false, GRID, RECS, COUNT);                                                                       \
     } while (0)
         const unsigned ep = ++h->sp_epoch;
         if (sp_level(h)) {
@@ -1768,7 +1739,6 @@ extern "C" int ipm_debug_ff_schedule(int32_t nblk, int32_t q, int32_t workers, u
     FFSchedule S;
     FFModel M;
     M.nstages = 512;                                          // K = 8192 (the headline size's formation), BK = 16 stages
-    if (const char* e = getenv("IPM_FF_DEBUG_NSTAGES")) M.nstages = std::max(q, atoi(e));
     if (!(getenv("IPM_FF_CHAIN_MODE") && atoi(getenv("IPM_FF_CHAIN_MODE")) == 0)) M.roles_calibration();
     ff_build_schedule(nblk, q, workers, M, S, std::max(q, 16));
     *count = (int32_t)S.items.size();
@@ -1917,8 +1887,7 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
     hipLaunchKernelGGL((sp_bwd_kernel<NT, SC>), dim3(GRID), dim3(NT), 0, h->stream, h->spF, ep, h->t2, out, RECS, COUNT)
 #define SP_SWEEP(WHICH, GRID, RECS, COUNT)                                                                                            \
     do {                                                                                                                             \
-        if (h->sp_threads == 64) { if (h->sp_sc1) WHICH(64, true, GRID, RECS, COUNT); else WHICH(64, false, GRID, RECS, COUNT); }     \
-        else { if (h->sp_sc1) WHICH(SPC_THREADS, true, GRID, RECS, COUNT); else WHICH(SPC_THREADS, false, GRID, RECS, COUNT); }       \
+        WHICH(SPC_THREADS, false, GRID, RECS, COUNT);                                                                                \
     } while (0)
         unsigned ep = ++h->sp_epoch;
         const size_t nlev = h->sp_lvlptr.size() > 0 ? h->sp_lvlptr.size() - 1 : 0;
@@ -2026,22 +1995,9 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         }
         // start late in the chain-bound tail: the three passes need ~0.2 ms, six steps of the chain.  Measured at 32 blocks
         // (it/s for a start at step 0 / 4 / 12 / 20 / 26 / 30): 199.5 / 199.6 / 200.6 / 201.0 / 203.1 / 200.5
-        const int rstep = h->residual_step >= 0 ? std::min(h->residual_step, h->nblk - 1) : h->nblk * 13 / 16;
+        const int rstep = h->nblk * 13 / 16;
         const int nG = h->grouped_trsv ? h->nblk / h->gsz : 0;
-        const int gstep = (h->overlap_ginv && nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
-        static const bool ff_overlap = !(getenv("IPM_FF_OVERLAP") && atoi(getenv("IPM_FF_OVERLAP")) == 0);
-        if (fused && !ff_overlap) {
-            // experiment: no residual-stream work beside the fused launch -- residuals, group inverses after it, in stream order
-            if ((rc = enqueue_form_factor(h, ev, -1, -1))) return rc;
-            h->fdone = nullptr;
-            if ((rc = enqueue_residuals(h))) return rc;
-            launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);
-            if ((rc = enqueue_group_inverses(h, 0, nG, nullptr))) return rc;
-            if ((rc = enqueue_predictor(h, nullptr, /*have_rhs=*/true))) return rc;
-            if ((rc = enqueue_corrector(h, nullptr))) return rc;
-            if ((rc = enqueue_update(h))) return rc;
-            return IPM_OK;
-        }
+        const int gstep = (nG >= 2 && (nG - 1) * h->gsz - 1 < rstep) ? (nG - 1) * h->gsz - 1 : -1;
         if (fused) { if ((rc = enqueue_form_factor(h, ev, rstep, gstep))) return rc; }
         else if ((rc = enqueue_factor(h, true, rstep, gstep))) return rc;
         h->fdone = nullptr;
@@ -2374,21 +2330,14 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     }
     bool first = true;
     int recovered = 0;
-    static const bool host_timing = getenv("IPM_HOST_TIMING") != nullptr;        // diagnostic: where the host thread spends a solve
-    double t_enq = 0.0, t_wait = 0.0;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    struct Report { const bool on; const double &a, &b; const ipm_handle* h; ~Report() { if (on) fprintf(stderr, "[ipm host] m=%lld: enqueue %.1f ms, wait %.1f ms\n", (long long)h->m, a * 1e3, b * 1e3); } } report{host_timing, t_enq, t_wait, h};
     for (;;) {
         // roll-back point: the first chunk (auto-regularize restart) and every chunk that can hit a poll time-out
         const bool snap = first || may_poll(h);
-        const double t0 = host_timing ? now() : 0.0;
         if (snap && (rc = enqueue_snapshot(h, 0))) return rc;
         for (int i = 0; i < chunk; ++i)
             if ((rc = enqueue_iteration(h, nullptr))) return rc;
-        const double t1 = host_timing ? now() : 0.0;
         bool tmo = false;
         if ((rc = read_scalars(h, &tmo))) return rc;
-        if (host_timing) { t_enq += t1 - t0; t_wait += now() - t1; }
         if (tmo) {
             if (!snap || ++recovered > 2) return fail(h, IPM_ERR_HIP, "hand-off time-out persists with stream events");
             poll_fallback(h);

@@ -78,7 +78,11 @@ enum {
      * backward substitution is ONE launch that walks the elimination tree.  It pays when the factor stays sparse
      * (STOCFOR3: 2.2e5 entries, tree height 36, against a chain of 131 dense 128-row blocks); ipm_order_rows reports
      * the numbers to decide with.  ipm_set_A_csc fails with IPM_ERR_INVALID_ARG when the structures exceed its caps. */
-    IPM_FLAG_SPARSE_FACTOR = 8
+    IPM_FLAG_SPARSE_FACTOR = 8,
+    /* The handle is created for ipm_solve_batch (the LOCKSTEP batch: iteration k of several LPs in the same launches): implies
+     * IPM_FLAG_SINGLE_STREAM | IPM_FLAG_NO_DEVICE_POLLING and block-step triangular solves, so that every launch of its iteration has
+     * a batched twin.  Such a handle still works with every other entry point (ipm_solve included: same arithmetic, one LP). */
+    IPM_FLAG_LOCKSTEP = 16
 };
 
 typedef struct ipm_handle ipm_handle;
@@ -189,6 +193,13 @@ int ipm_iterate(ipm_handle* h, int32_t n_steps, ipm_stats* stats);
  * max_iter iterations were taken.  tol_p/tol_d/tol_gap = e1/e2/e3 of main.py:772-774. */
 int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t max_iter,
               ipm_stats* stats);
+/* The LOCKSTEP BATCH of the batched-LP mode (the driver loop of script.py:147-173 over independent LPs, on one GPU): ipm_solve for n
+ * handles AT ONCE, iteration k of all of them in the same launches (csrc/lockstep.h).  Every handle must have been created with
+ * IPM_FLAG_LOCKSTEP on the same device, hold a sparse A of more than 128 rows on the dense-tile factor (not IPM_FLAG_SPARSE_FACTOR)
+ * and have A, b, c and a state set.  Same arguments and per-handle semantics as ipm_solve (stop test, iteration cap, automatic
+ * Tikhonov shift); stats[i] (may be NULL) describes handle i, with solve_ms the device time of the whole batch.  The arithmetic
+ * of a handle is exactly that of ipm_solve on it alone: bit-identical iterates.  Launched on the first handle's stream. */
+int ipm_solve_batch(ipm_handle** handles, int32_t n, double tol_p, double tol_d, double tol_gap, int32_t max_iter, ipm_stats* stats);
 /* Per-iteration records of the last ipm_solve / ipm_iterate, oldest first: min(iterations, IPM_HISTORY_CAPACITY,
  * capacity) records are written to `out` (host) and their number to *count. */
 int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32_t* count);

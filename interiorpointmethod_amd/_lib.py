@@ -18,7 +18,7 @@ EXPORTS = [
     "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc", "ipm_workspace_bytes_opts",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
-    "ipm_iterate", "ipm_solve", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
+    "ipm_iterate", "ipm_solve", "ipm_solve_batch", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
     "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps", "ipm_debug_ff_schedule", "ipm_debug_ff_trace", "ipm_debug_get_block_inverse",
 ]
 
@@ -28,6 +28,7 @@ FLAG_NO_DEVICE_POLLING = 1      # include/ipm_hip.h: IPM_FLAG_NO_DEVICE_POLLING
 FLAG_NO_AUTO_REGULARIZE = 2     # include/ipm_hip.h: IPM_FLAG_NO_AUTO_REGULARIZE
 FLAG_SINGLE_STREAM = 4          # include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM
 FLAG_SPARSE_FACTOR = 8          # include/ipm_hip.h: IPM_FLAG_SPARSE_FACTOR
+FLAG_LOCKSTEP = 16              # include/ipm_hip.h: IPM_FLAG_LOCKSTEP
 ERR_WORKSPACE = -4
 ABI_VERSION = 4
 HISTORY_CAPACITY = 1024         # IPM_HISTORY_CAPACITY
@@ -121,6 +122,7 @@ def load():
     lib.ipm_newton_direction.argtypes = [vp, C.c_int, pd, pd, pd, C.POINTER(Stats)]
     lib.ipm_iterate.argtypes = [vp, i32, C.POINTER(Stats)]
     lib.ipm_solve.argtypes = [vp, dbl, dbl, dbl, i32, C.POINTER(Stats)]
+    lib.ipm_solve_batch.argtypes = [C.POINTER(vp), i32, dbl, dbl, dbl, i32, C.POINTER(Stats)]
     lib.ipm_get_history.argtypes = [vp, C.POINTER(IterRecord), i32, C.POINTER(i32)]
     lib.ipm_get_schedule.argtypes = [vp, C.POINTER(i32)]
     lib.ipm_order_rows.argtypes = [i64, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), pd]

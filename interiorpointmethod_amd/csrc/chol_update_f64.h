@@ -16,7 +16,7 @@
 
 namespace ipm {
 
-__global__ __launch_bounds__(256, 2) void chol_update_kernel(GemmNT g) {
+__device__ __forceinline__ void chol_update_kernel_body(GemmNT g, const unsigned bx_, const unsigned gx_) {
     constexpr int BM = 128, BK = 16, LDT = BK + 2, RSTEP = 32;
     if (g.done && *g.done) {
         if (g.signal && threadIdx.x == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(GemmNT g) {
 
     int ti, tj;
     {
-        const int bid = xcd_remap(blockIdx.x, gridDim.x) + g.tile_offset;
+        const int bid = xcd_remap(bx_, gx_) + g.tile_offset;
         if (g.tile_order) {
             const int packed = g.tile_order[bid];
             ti = packed >> 16; tj = packed & 0xffff;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(GemmNT g) {
         }
     }
 }
+__global__ __launch_bounds__(256, 2) void chol_update_kernel(GemmNT g) { chol_update_kernel_body(g, blockIdx.x, gridDim.x); }
 
 // Drop-in for launch_gemm_nt<128,128,16,2,2>(g, stream, nullptr, 512, skip_first) on the shapes the trailing update uses:
 // no scaling, no split-K, no batch, no wait, no unit diagonal; M, N multiples of 128, K of 16.  Anything else -> the
@@ -189,6 +190,7 @@ inline hipError_t launch_chol_update(GemmNT g, hipStream_t stream, int skip_firs
     if (tiles <= 0) return hipSuccess;
     g.tile_offset = skip_first;
     g.n_direct = tiles; g.split_p = 1; g.chunk_stages = g.K / 16; g.slab = nullptr; g.batch = 1; g.batch2 = 1;
+    if (g_gemm_recorder) { g_gemm_recorder->fn(g_gemm_recorder->ctx, -1, 0, 0, 0, 0, g, tiles); return hipSuccess; }      // (bm = -1: this kernel)
     hipLaunchKernelGGL(chol_update_kernel, dim3(tiles), dim3(256), 0, stream, g);
     return hipGetLastError();
 }

@@ -339,6 +339,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmNT g) {
 
 constexpr int kSlabTiles = 512;      // capacity of the split-K slab workspace, in BM x BN tiles
 
+// Lockstep batch (lockstep.h): while a handle's launch sequence is being RECORDED, the GEMM launchers hand the finished argument
+// struct and grid to this hook instead of launching (thread local: a recording belongs to the calling host thread).
+struct GemmRecorder { void (*fn)(void* ctx, int bm, int bn, int bk, int wm, int wn, const GemmNT& g, int grid); void* ctx; };
+inline thread_local GemmRecorder* g_gemm_recorder = nullptr;
+
 // slots = workgroups resident at once (2 per CU for the 128x128 tile).  slab may be null (no split).
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nullptr, int slots = 512,
@@ -368,6 +373,7 @@ inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nu
             }
         }
     }
+    if (g_gemm_recorder && !g.w && !g.slab && g.batch == 1 && g.batch2 == 1) { g_gemm_recorder->fn(g_gemm_recorder->ctx, BM, BN, BK, WAVES_M, WAVES_N, g, grid); return hipSuccess; }
     if (g.w)
         hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), dim3(grid, g.batch, g.batch2),
                            dim3(64 * WAVES_M * WAVES_N), 0, stream, g);

@@ -29,6 +29,7 @@
 #include "sparse_symbolic.h"
 #include "vector_ops.h"
 #include "form_factor.h"
+#include "lockstep.h"
 
 #include <algorithm>
 #include <atomic>
@@ -168,8 +169,24 @@ struct ipm_handle {
     int profiling = 0;                    // 0 off, 1 events around the A D^2 A^T kernel only, 2 every phase
     double phase_ms[4] = {0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // lockstep batch (lockstep.h, ipm_solve_batch): while non-null, every launch site of the single-stream iteration path RECORDS
+    // (kernel type, grid, arguments) here instead of launching
+    std::vector<struct LsLaunch>* ls_rec = nullptr;
+    bool ls_cut = false;                  // a launch without a lockstep twin was met while recording
+    int lockstep = 0;                     // IPM_FLAG_LOCKSTEP: created for ipm_solve_batch (block-step substitutions: every launch of the iteration is recordable)
     char err[512] = "";
 };
+struct LsLaunch { int type; LsRec rec; };
+template <class A> static bool ls_push(ipm_handle* h, int type, unsigned gridx, const A& a, unsigned lds = 0) {
+    if (!h->ls_rec) return false;
+    static_assert(sizeof(A) <= LS_ARG_BYTES, "LsRec::args too small");
+    LsLaunch L;
+    memset(&L, 0, sizeof L);
+    L.type = type; L.rec.gridx = gridx; L.rec.lds = lds;
+    memcpy(L.rec.args, &a, sizeof(A));
+    h->ls_rec->push_back(L);
+    return true;
+}
 
 static int fail(ipm_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -461,8 +478,10 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     if (const char* e = getenv("IPM_LOOKAHEAD")) h->lookahead = atoi(e);
+    if (h->opt.flags & IPM_FLAG_LOCKSTEP) { h->lockstep = 1; h->opt.flags |= IPM_FLAG_SINGLE_STREAM | IPM_FLAG_NO_DEVICE_POLLING; }
     if (h->opt.flags & IPM_FLAG_SINGLE_STREAM) h->lookahead = 0;
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
+    if (h->lockstep) h->grouped_trsv = 0;      // block-step substitutions: every launch of the iteration has a lockstep twin (lockstep.h)
     if (h->no_dense) h->grouped_trsv = 0;      // the sparse factor has its own sweeps; a dense entry point on such a handle solves block by block
     h->gsz = 0;
     if (h->grouped_trsv) {
@@ -1162,6 +1181,8 @@ static void launch_gemv_n(ipm_handle* h, const double* v, double sa, double sb, 
                           hipStream_t st = nullptr) {
     if (!st) st = h->stream;
     if (h->sparse) {
+        const LsSpmv p{sparse_view(h), (int)h->mp, v, sa, sb, add, out, &h->sc->done};
+        if (ls_push(h, LS_SPMV_CSR, (unsigned)((h->mp + 15) / 16), p)) return;
         hipLaunchKernelGGL(spmv_csr_kernel, dim3((unsigned)((h->mp + 15) / 16)), dim3(256), 0, st, sparse_view(h),
                            (int)h->mp, v, sa, sb, add, out, &h->sc->done);
         return;
@@ -1172,6 +1193,8 @@ static void launch_gemv_n(ipm_handle* h, const double* v, double sa, double sb, 
 static void launch_gemv_t(ipm_handle* h, const double* u, hipStream_t st = nullptr) {
     if (!st) st = h->stream;
     if (h->sparse) {
+        const LsSpmvT p{sparse_view(h), (int)h->np, u, h->atp, &h->sc->done};
+        if (ls_push(h, LS_SPMV_CSC_T, (unsigned)((h->np + 15) / 16), p)) return;
         hipLaunchKernelGGL(spmv_csc_t_kernel, dim3((unsigned)((h->np + 15) / 16)), dim3(256), 0, st, sparse_view(h),
                            (int)h->np, u, h->atp, &h->sc->done);
         return;
@@ -1187,8 +1210,8 @@ static int enqueue_residuals(ipm_handle* h, hipStream_t st = nullptr) {
     VecArgs a = vec_args(h);
     launch_gemv_n(h, h->x, 1.0, -1.0, h->b, h->rb, st);             // r_b = A x - b
     launch_gemv_t(h, h->y, st);                                     // A^T y (partials)
-    hipLaunchKernelGGL(prepare_kernel, dim3(h->vblk), dim3(VBLK), 0, st, a);
-    hipLaunchKernelGGL(stop_test_kernel, dim3(1), dim3(64), 0, st, a);
+    if (!ls_push(h, LS_PREPARE, (unsigned)h->vblk, LsVecA{a, 0})) hipLaunchKernelGGL(prepare_kernel, dim3(h->vblk), dim3(VBLK), 0, st, a);
+    if (!ls_push(h, LS_STOP_TEST, 1u, LsVecA{a, 0})) hipLaunchKernelGGL(stop_test_kernel, dim3(1), dim3(64), 0, st, a);
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }
@@ -1255,19 +1278,24 @@ static int enqueue_form(ipm_handle* h, const double* d, bool dense_image = false
     if (int rc_ = ensure_dense_B(h)) return rc_;
     if (h->sparse && h->list_form) {
         const int64_t nB = h->mp * h->mp;                       // even (mp is a multiple of 128)
-        hipLaunchKernelGGL(zero_unless_done_kernel, dim3((unsigned)std::min<int64_t>((nB / 2 + 255) / 256, 4096)), dim3(256), 0, h->stream,
-                           h->B, nB, &h->sc->done);
+        const unsigned zgrid = (unsigned)std::min<int64_t>((nB / 2 + 255) / 256, 4096);
+        if (!ls_push(h, LS_ZERO, zgrid, LsZero{h->B, nB, &h->sc->done}))
+            hipLaunchKernelGGL(zero_unless_done_kernel, dim3(zgrid), dim3(256), 0, h->stream, h->B, nB, &h->sc->done);
         const int work = h->sm_nb + (int)(h->mp - h->m);
-        hipLaunchKernelGGL(adat_list_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, h->sm_bptr, h->ls_bi, h->ls_bk,
-                           h->sm_bcol, h->sm_bcoef, h->ls_bak, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done);
+        const LsAdatList pl{h->sm_bptr, h->ls_bi, h->ls_bk, h->sm_bcol, h->sm_bcoef, h->ls_bak, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done};
+        if (!ls_push(h, LS_ADAT_LIST, (unsigned)((work + 255) / 256), pl))
+            hipLaunchKernelGGL(adat_list_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, h->stream, h->sm_bptr, h->ls_bi, h->ls_bk,
+                               h->sm_bcol, h->sm_bcoef, h->ls_bak, h->sm_nb, d, h->B, h->mp, (int)h->m, (int)h->mp, &h->sc->done);
         HIP_TRY(h, hipGetLastError());
         return IPM_OK;
     }
     if (h->sparse) {
+        const LsAdatSp ps{sparse_view(h), d, h->B, h->mp, (int)h->mp, &h->sc->done};
         if (h->mp <= SP_LDS_MAX_MP) {          // dynamic-LDS attribute set per device in ipm_create
-            hipLaunchKernelGGL(adat_sparse_kernel, dim3((unsigned)h->mp), dim3(256), (size_t)h->mp * sizeof(double), h->stream,
-                               sparse_view(h), d, h->B, h->mp, (int)h->mp, &h->sc->done);
-        } else {
+            if (!ls_push(h, LS_ADAT_SPARSE, (unsigned)h->mp, ps, (unsigned)(h->mp * sizeof(double))))
+                hipLaunchKernelGGL(adat_sparse_kernel, dim3((unsigned)h->mp), dim3(256), (size_t)h->mp * sizeof(double), h->stream,
+                                   sparse_view(h), d, h->B, h->mp, (int)h->mp, &h->sc->done);
+        } else if (!ls_push(h, LS_ADAT_SPARSE_GLOBAL, (unsigned)h->mp, ps)) {
             hipLaunchKernelGGL(adat_sparse_global_kernel, dim3((unsigned)h->mp), dim3(256), 0, h->stream, sparse_view(h), d,
                                h->B, h->mp, (int)h->mp, &h->sc->done);
         }
@@ -1333,7 +1361,8 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
     const int* done = h->fdone ? h->fdone : &h->sc->done;
     use_env = use_env && h->use_env;
     // threshold scale = max diag over the TRUE rows only (padding rows carry a unit diagonal)
-    hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
+    if (!ls_push(h, LS_MAXDIAG, 1u, LsMaxdiag{h->B, h->mp, (int)h->m, &h->sc->maxdiag, done}))
+        hipLaunchKernelGGL(maxdiag_kernel, dim3(1), dim3(256), 0, h->stream, h->B, h->mp, (int)h->m, &h->sc->maxdiag, done);
     const bool la = h->lookahead != 0 && h->nblk > 2 && h->stream2 != nullptr;
     // group size of the two-level schedule.  Measured (factor, ms): 16384 x 32768: 39.7 / 34.9 / 33.4 / 32.9 / 32.5 for groups
     // of 1 / 2 / 3 / 4 / 6; 8192 x 16384: 7.87 / 7.46 / 7.34 / 7.34 for 1 / 2 / 3 / 4; but 4096 x 8192: 2.21 -> 2.36 with groups
@@ -1376,7 +1405,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
             hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
-        } else {
+        } else if (!ls_push(h, LS_POTRF, 1u, pd)) {
             hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         }
         if (k == ginv_step) {
@@ -1852,13 +1881,13 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out, hipEvent
         for (int k = k_left; k < h->nblk; ++k) {
             a.k = k;
             const int nb = h->use_env ? h->env_last[k] - k + 1 : h->nblk - k;
-            hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb), dim3(256), 0, h->stream, a);
+            if (!ls_push(h, LS_TRSV_FWD, (unsigned)nb, a)) hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb), dim3(256), 0, h->stream, a);
         }
         a.r = z; a.z = out;
         for (int k = h->nblk - 1; k >= k_left; --k) {
             a.k = k;
             a.j0 = h->use_env ? h->env_first[k] : 0;
-            hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k - a.j0 + 1), dim3(256), 0, h->stream, a);
+            if (!ls_push(h, LS_TRSV_BWD, (unsigned)(k - a.j0 + 1), a)) hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k - a.j0 + 1), dim3(256), 0, h->stream, a);
         }
     }
     for (int g = nG - 1; g >= 0; --g) {                                   // backward: L^T w = z
@@ -1922,13 +1951,13 @@ static int enqueue_potrs(ipm_handle* h, double* r, double* out, hipEvent_t wait_
     for (int k = 0; k < h->nblk; ++k) {
         a.k = k;
         const int nb = h->use_env ? h->env_last[k] - k + 1 : h->nblk - k;
-        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb), dim3(256), 0, h->stream, a);
+        if (!ls_push(h, LS_TRSV_FWD, (unsigned)nb, a)) hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3(nb), dim3(256), 0, h->stream, a);
     }
     a.r = h->t2; a.z = out;
     for (int k = h->nblk - 1; k >= 0; --k) {
         a.k = k;
         a.j0 = h->use_env ? h->env_first[k] : 0;
-        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k - a.j0 + 1), dim3(256), 0, h->stream, a);
+        if (!ls_push(h, LS_TRSV_BWD, (unsigned)(k - a.j0 + 1), a)) hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3(k - a.j0 + 1), dim3(256), 0, h->stream, a);
     }
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
@@ -1942,29 +1971,29 @@ static int enqueue_predictor(ipm_handle* h, hipEvent_t* ev, bool have_rhs = fals
     if (rc) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     launch_gemv_t(h, h->dya);
-    hipLaunchKernelGGL(direction_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a, 0);
+    if (!ls_push(h, LS_DIRECTION, (unsigned)h->vblk, LsVecA{a, 0})) hipLaunchKernelGGL(direction_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a, 0);
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }
 
 static int enqueue_corrector(ipm_handle* h, hipEvent_t* ev) {
     VecArgs a = vec_args(h);
-    hipLaunchKernelGGL(mu_aff_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
-    hipLaunchKernelGGL(corrector_rhs_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
+    if (!ls_push(h, LS_MU_AFF, (unsigned)h->vblk, LsVecA{a, 0})) hipLaunchKernelGGL(mu_aff_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
+    if (!ls_push(h, LS_CORR_RHS, (unsigned)h->vblk, LsVecA{a, 0})) hipLaunchKernelGGL(corrector_rhs_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
     launch_gemv_n(h, h->v, -1.0, -1.0, h->rb, h->t1);
     if (ev) HIP_TRY(h, hipEventRecord(ev[0], h->stream));
     int rc = enqueue_potrs(h, h->t1, h->dy);
     if (rc) return rc;
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], h->stream));
     launch_gemv_t(h, h->dy);
-    hipLaunchKernelGGL(direction_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a, 1);
+    if (!ls_push(h, LS_DIRECTION, (unsigned)h->vblk, LsVecA{a, 1})) hipLaunchKernelGGL(direction_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a, 1);
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }
 
 static int enqueue_update(ipm_handle* h) {
     VecArgs a = vec_args(h);
-    hipLaunchKernelGGL(update_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
+    if (!ls_push(h, LS_UPDATE, (unsigned)h->vblk, LsVecA{a, 0})) hipLaunchKernelGGL(update_kernel, dim3(h->vblk), dim3(VBLK), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
 }
@@ -2125,10 +2154,10 @@ __global__ __launch_bounds__(256) void snapshot_kernel(double* x, double* y, dou
         if (gid == 0) *ssc = *sc;
     }
 }
-static int enqueue_snapshot(ipm_handle* h, int restore) {
+static int enqueue_snapshot(ipm_handle* h, int restore, hipStream_t st = nullptr) {
     const int64_t mx = h->np > h->mp ? h->np : h->mp;
     const unsigned grid = (unsigned)std::min<int64_t>((mx + 255) / 256, 256);
-    hipLaunchKernelGGL(snapshot_kernel, dim3(grid), dim3(256), 0, h->stream, h->x, h->y, h->s, h->sc, h->snap, (int)h->np,
+    hipLaunchKernelGGL(snapshot_kernel, dim3(grid), dim3(256), 0, st ? st : h->stream, h->x, h->y, h->s, h->sc, h->snap, (int)h->np,
                        (int)h->mp, restore);
     HIP_TRY(h, hipGetLastError());
     return IPM_OK;
@@ -2361,6 +2390,148 @@ extern "C" int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_g
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     fill_stats(h, stats, ms);
+    return IPM_OK;
+}
+
+
+// ------------------------------------------------------------------------------- lockstep batch (lockstep.h)
+static void ls_gemm_hook(void* ctx, int bm, int bn, int bk, int wm, int wn, const GemmNT& g, int grid) {
+    ipm_handle* h = (ipm_handle*)ctx;
+    int type = -1;
+    if (bm == -1) type = LS_CHOL_UPDATE;
+    else if (bm == 32 && bn == 128 && bk == 32 && wm == 1 && wn == 8) type = LS_GEMM_32_128_32;
+    else if (bm == 64 && bn == 64 && bk == 16) type = LS_GEMM_64_64_16;
+    else if (bm == 64 && bn == 128 && bk == 16) type = LS_GEMM_64_128_16;
+    else if (bm == 128 && bn == 128 && bk == 16 && wm == 2 && wn == 2) type = LS_GEMM_128_128_16;
+    else if (bm == 32 && bn == 32 && bk == 32) type = LS_GEMM_32_32_32;
+    if (type < 0 || g.wait_on || g.signal) { h->ls_cut = true; return; }      // not recordable: ls_record_program reports it
+    ls_push(h, type, (unsigned)grid, g);
+}
+static bool ls_eligible(const ipm_handle* h) {
+    return h->lockstep && h->sparse && !h->small && !h->spf && h->lookahead == 0 && h->stream2 == nullptr && !h->grouped_trsv && h->B && h->invD &&
+           h->haveA && h->haveBC && h->haveState;
+}
+// the launch sequence of ONE iteration of the handle, recorded (nothing is launched)
+static int ls_record_program(ipm_handle* h, std::vector<LsLaunch>& prog) {
+    prog.clear();
+    GemmRecorder rec{ls_gemm_hook, h};
+    h->ls_rec = &prog; h->ls_cut = false;
+    g_gemm_recorder = &rec;
+    const int rc = enqueue_iteration(h, nullptr);
+    g_gemm_recorder = nullptr;
+    const bool cut = h->ls_cut;
+    h->ls_rec = nullptr;
+    if (rc) return rc;
+    if (cut || prog.empty()) return fail(h, IPM_ERR_STATE, "ipm_solve_batch: the handle's iteration holds a launch without a lockstep twin");
+    return IPM_OK;
+}
+struct LsStep { int type; unsigned count, gridx, lds; size_t offset; };      // `count` records from `offset` on
+// Merge the programs (each LP's order preserved) into global steps of one kernel type: the LP with the most launches left sets
+// the type of the next step, every LP whose next launch is of that type joins it.
+static void ls_merge(const std::vector<const std::vector<LsLaunch>*>& progs, std::vector<LsStep>& steps, std::vector<LsRec>& recs) {
+    steps.clear(); recs.clear();
+    const size_t n = progs.size();
+    std::vector<size_t> pos(n, 0);
+    for (;;) {
+        size_t lead = n, left = 0;
+        for (size_t i = 0; i < n; ++i) { const size_t l = progs[i]->size() - pos[i]; if (l > left) { left = l; lead = i; } }
+        if (lead == n) break;
+        LsStep st;
+        st.type = (*progs[lead])[pos[lead]].type; st.count = 0; st.gridx = 0; st.lds = 0; st.offset = recs.size();
+        for (size_t i = 0; i < n; ++i) {
+            if (pos[i] >= progs[i]->size()) continue;
+            const LsLaunch& L = (*progs[i])[pos[i]];
+            if (L.type != st.type) continue;
+            recs.push_back(L.rec);
+            st.count++; st.gridx = std::max(st.gridx, L.rec.gridx); st.lds = std::max(st.lds, L.rec.lds);
+            ++pos[i];
+        }
+        steps.push_back(st);
+    }
+}
+
+extern "C" int ipm_solve_batch(ipm_handle** hs, int32_t n, double tol_p, double tol_d, double tol_gap, int32_t max_iter, ipm_stats* stats) {
+    if (!hs || n <= 0 || max_iter < 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: bad arguments");
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: NULL handle");
+        if (hs[i]->device != hs[0]->device) return fail(hs[i], IPM_ERR_INVALID_ARG, "ipm_solve_batch: handles on different devices");
+        if (!ls_eligible(hs[i])) return fail(hs[i], IPM_ERR_STATE, "ipm_solve_batch: handle %d is not a lockstep handle (IPM_FLAG_LOCKSTEP, sparse A, more than 128 rows, dense-tile factor, A / b / c / state set)", i);
+    }
+    ipm_handle* h0 = hs[0];
+    HIP_TRY(h0, hipSetDevice(h0->device));
+    hipStream_t S = h0->stream;
+    static std::atomic<bool> attr_set[MAX_DEVICES];
+    if (h0->device < MAX_DEVICES && !attr_set[h0->device].load(std::memory_order_acquire)) {
+        HIP_TRY(h0, hipFuncSetAttribute((const void*)ls_adat_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8));
+        attr_set[h0->device].store(true, std::memory_order_release);
+    }
+    int chunk = 1;
+    for (int i = 0; i < n; ++i) {
+        ipm_handle* h = hs[i];
+        if (h->stream != S) HIP_TRY(h, hipStreamSynchronize(h->stream));      // everything the handle did on its own stream is complete
+        h->predictor_valid = false; h->fresh_state = false;
+        if (h->auto_reg) { h->auto_reg = 0; h->shift_rel = h->opt.regularize; }
+        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, S, h->sc, tol_p, tol_d, tol_gap, h->opt.eta, max_iter, 0, 1);
+        int rc = enqueue_snapshot(h, 0, S);                     // roll-back point of the automatic Tikhonov shift (first chunk)
+        if (rc) return rc;
+        chunk = std::max(chunk, (int)h->opt.check_every);
+    }
+    HIP_TRY(h0, hipEventRecord(h0->ev0, S));
+    std::vector<std::vector<LsLaunch>> prog((size_t)n);
+    for (int i = 0; i < n; ++i) { int rc = ls_record_program(hs[i], prog[(size_t)i]); if (rc) return rc; }
+    std::vector<int> active((size_t)n);
+    for (int i = 0; i < n; ++i) active[(size_t)i] = i;
+    std::vector<char> first((size_t)n, 1);
+    std::vector<LsStep> steps;
+    std::vector<LsRec> recs;
+    LsRec* d_recs = nullptr;
+    size_t d_cap = 0;
+    struct Free { ipm_handle* h; LsRec** p; ~Free() { if (*p) dev_free(h->device, h->stream, *p); } } guard{h0, &d_recs};
+    bool dirty = true;
+    while (!active.empty()) {
+        if (dirty) {
+            std::vector<const std::vector<LsLaunch>*> ps;
+            for (int i : active) ps.push_back(&prog[(size_t)i]);
+            ls_merge(ps, steps, recs);
+            HIP_TRY(h0, hipStreamSynchronize(S));                   // (the table of the previous schedule may still be read)
+            if (recs.size() > d_cap) {
+                if (d_recs) dev_free(h0->device, S, d_recs);
+                d_recs = nullptr; d_cap = recs.size() + recs.size() / 4;
+                HIP_TRY(h0, dev_malloc(h0->device, S, (void**)&d_recs, sizeof(LsRec) * d_cap));
+            }
+            HIP_TRY(h0, hipMemcpyAsync(d_recs, recs.data(), sizeof(LsRec) * recs.size(), hipMemcpyHostToDevice, S));
+            HIP_TRY(h0, hipStreamSynchronize(S));                   // (`recs` is reused)
+            dirty = false;
+        }
+        for (int c = 0; c < chunk; ++c)
+            for (const LsStep& st : steps) HIP_TRY(h0, ls_launch(st.type, d_recs + st.offset, st.count, st.gridx, st.lds, S));
+        for (int i : active) HIP_TRY(hs[i], hipMemcpyAsync(hs[i]->h_sc, hs[i]->sc, sizeof(Scalars), hipMemcpyDeviceToHost, S));
+        HIP_TRY(h0, hipStreamSynchronize(S));
+        std::vector<int> keep;
+        for (int i : active) {
+            ipm_handle* h = hs[i];
+            const bool may_auto = h->opt.regularize == 0.0 && !(h->opt.flags & IPM_FLAG_NO_AUTO_REGULARIZE);
+            if (first[(size_t)i] && may_auto && h->h_sc->k > 0 && (double)h->h_sc->fixed_first > 0.05 * (double)h->m) {
+                // > 5 % dependent rows (QAP family): restart this LP from its start state with the 1e-14 Tikhonov shift (as ipm_solve does)
+                h->shift_rel = 1e-14; h->auto_reg = 1;
+                int rc = enqueue_snapshot(h, 1, S);
+                if (!rc) rc = ls_record_program(h, prog[(size_t)i]);
+                if (rc) return rc;
+                first[(size_t)i] = 0; dirty = true;
+                keep.push_back(i);
+                continue;
+            }
+            first[(size_t)i] = 0;
+            if (h->h_sc->done) { dirty = true; continue; }
+            keep.push_back(i);
+        }
+        active.swap(keep);
+    }
+    HIP_TRY(h0, hipEventRecord(h0->ev1, S));
+    HIP_TRY(h0, hipEventSynchronize(h0->ev1));
+    float ms = 0.f;
+    HIP_TRY(h0, hipEventElapsedTime(&ms, h0->ev0, h0->ev1));
+    if (stats) for (int i = 0; i < n; ++i) fill_stats(hs[i], &stats[i], ms);
     return IPM_OK;
 }
 

@@ -496,8 +496,8 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(PotrfDiag a) {
 }
 
 // max of the diagonal of an n x n matrix (single workgroup; n <= a few 10^4)
-__global__ __launch_bounds__(256) void maxdiag_kernel(const double* B, int64_t ld, int n, double* out,
-                                                      const int* done) {
+__device__ __forceinline__ void maxdiag_kernel_body(const double* B, int64_t ld, int n, double* out,
+                                                      const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
     __shared__ double red[256];
     double mx = -1.7976931348623157e308;
@@ -513,6 +513,8 @@ __global__ __launch_bounds__(256) void maxdiag_kernel(const double* B, int64_t l
     }
     if (threadIdx.x == 0) *out = red[0];
 }
+__global__ __launch_bounds__(256) void maxdiag_kernel(const double* B, int64_t ld, int n, double* out,
+                                                      const int* done) { maxdiag_kernel_body(B, ld, n, out, done, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------
 // Triangular solves with the factor (L in the lower triangle of B, inv(L_kk) per block).
@@ -598,19 +600,19 @@ struct TrsvStep {
 // forward step k: z_k = inv(L_kk) r_k ; r_i -= L_ik z_k for i > k.  grid = nblk - k.
 // Both 128 x 128 blocks are fetched into registers up front, so the second product does not pay a
 // second memory latency after z_k is known.
-__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(TrsvStep a) {
+__device__ __forceinline__ void trsv_fwd_step_kernel_body(TrsvStep a, const unsigned bx_, const unsigned gx_) {
     if (a.done && *a.done) return;
     __shared__ double vs[NB], zs[NB], us[NB];
     const int tid = threadIdx.x;
-    const int i = a.k + blockIdx.x;
+    const int i = a.k + bx_;
     BlockRegs RI, RL;
     block_load(RI, a.inv + (int64_t)a.k * NB * NB, NB);
-    if (blockIdx.x != 0) block_load(RL, a.L + (int64_t)i * NB * a.ld + (int64_t)a.k * NB, a.ld);
+    if (bx_ != 0) block_load(RL, a.L + (int64_t)i * NB * a.ld + (int64_t)a.k * NB, a.ld);
     if (tid < NB) vs[tid] = a.r[(int64_t)a.k * NB + tid];
     __syncthreads();
     block_gemv_n(RI, vs, zs);
     __syncthreads();
-    if (blockIdx.x == 0) {
+    if (bx_ == 0) {
         if (tid < NB) a.z[(int64_t)a.k * NB + tid] = zs[tid];
         return;
     }
@@ -618,15 +620,16 @@ __global__ __launch_bounds__(256) void trsv_fwd_step_kernel(TrsvStep a) {
     __syncthreads();
     if (tid < NB) a.r[(int64_t)i * NB + tid] -= us[tid];
 }
+__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(TrsvStep a) { trsv_fwd_step_kernel_body(a, blockIdx.x, gridDim.x); }
 
 // backward step k (descending): w_k = inv(L_kk)^T z_k ; z_j -= L_kj^T w_k for j0 <= j < k. grid = k-j0+1.
 // Block j == k writes w_k to `z` (the solution); blocks j < k update the running rhs `r`.
-__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) {
+__device__ __forceinline__ void trsv_bwd_step_kernel_body(TrsvStep a, const unsigned bx_, const unsigned gx_) {
     if (a.done && *a.done) return;
     __shared__ double vs[NB], ws[NB], us[NB];
     __shared__ __attribute__((aligned(16))) double scratch[16 * NB];
     const int tid = threadIdx.x;
-    const int j = a.j0 + blockIdx.x;
+    const int j = a.j0 + bx_;
     BlockRegs RI, RL;
     block_load(RI, a.inv + (int64_t)a.k * NB * NB, NB);
     if (j != a.k) block_load(RL, a.L + (int64_t)a.k * NB * a.ld + (int64_t)j * NB, a.ld);
@@ -640,5 +643,6 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) {
     block_gemv_t(RL, ws, us, scratch);
     if (tid < NB) a.r[(int64_t)j * NB + tid] -= us[tid];
 }
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(TrsvStep a) { trsv_bwd_step_kernel_body(a, blockIdx.x, gridDim.x); }
 
 }  // namespace ipm

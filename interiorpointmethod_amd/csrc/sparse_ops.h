@@ -28,11 +28,11 @@ struct SparseA {
 constexpr int SP_LDS_MAX_MP = 19456;      // 152 KB accumulator row fits the 160 KB LDS
 
 // B[row][:] = sum_j a_rj d_j A[:,j]^T  for row < m; padding rows get e_row.  grid = mp workgroups.
-__global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const double* __restrict__ d, double* B,
-                                                          int64_t ldb, int mp, const int* done) {
+__device__ __forceinline__ void adat_sparse_kernel_body(SparseA A, const double* __restrict__ d, double* B,
+                                                          int64_t ldb, int mp, const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
     extern __shared__ __attribute__((aligned(16))) double acc[];          // mp doubles
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = bx_, tid = threadIdx.x;
     for (int k = tid; k < mp; k += 256) acc[k] = 0.0;
     __syncthreads();
     if (row < A.m) {
@@ -66,14 +66,17 @@ __global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const doubl
     for (int k = tid * 2; k < mp; k += 512)
         *reinterpret_cast<f64x2*>(out + k) = (f64x2){acc[k], acc[k + 1]};
 }
+__global__ __launch_bounds__(256) void adat_sparse_kernel(SparseA A, const double* __restrict__ d, double* B,
+                                                          int64_t ldb, int mp, const int* done) { adat_sparse_kernel_body(A, d, B, ldb, mp, done, blockIdx.x, gridDim.x); }
 
 // zero an n-double buffer unless the solve is done (a plain memset would wipe the factor of a converged solve when
 // iterations enqueued past convergence run as no-ops)
-__global__ __launch_bounds__(256) void zero_unless_done_kernel(double* p, int64_t n, const int* done) {
+__device__ __forceinline__ void zero_unless_done_kernel_body(double* p, int64_t n, const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2, st = (int64_t)gridDim.x * 512;
+    const int64_t i = ((int64_t)bx_ * 256 + threadIdx.x) * 2, st = (int64_t)gx_ * 512;
     for (int64_t k = i; k < n; k += st) *reinterpret_cast<f64x2*>(p + k) = (f64x2){0.0, 0.0};
 }
+__global__ __launch_bounds__(256) void zero_unless_done_kernel(double* p, int64_t n, const int* done) { zero_unless_done_kernel_body(p, n, done, blockIdx.x, gridDim.x); }
 
 // B from the PRODUCT LIST (built once on the host, ipm_set_A_csc): entry e = (bi[e], bk[e]) of A diag(d) A^T is
 // sum_t (bai[t] d[bcol[t]]) bak[t], t in [bptr[e], bptr[e+1]) -- one thread per entry, terms in ascending column order,
@@ -83,13 +86,13 @@ __global__ __launch_bounds__(256) void zero_unless_done_kernel(double* p, int64_
 // nb .. nb + (mp - m) - 1 put the unit diagonal on the padding rows.  Replaces adat_sparse_kernel for sparse handles up
 // to 1536 padded rows (that kernel gives every row of B a workgroup that walks the row's nonzeros one dependent load
 // at a time); beyond that the zero fill of the dense B costs what the list saves.
-__global__ __launch_bounds__(256) void adat_list_kernel(const int* __restrict__ bptr, const int* __restrict__ bi,
+__device__ __forceinline__ void adat_list_kernel_body(const int* __restrict__ bptr, const int* __restrict__ bi,
                                                         const int* __restrict__ bk, const int* __restrict__ bcol,
                                                         const double* __restrict__ bai, const double* __restrict__ bak, int nb,
                                                         const double* __restrict__ d, double* B, int64_t ldb, int m, int mp,
-                                                        const int* done) {
+                                                        const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bx_ * 256 + threadIdx.x;
     if (e < nb) {
         // the terms in ascending order, eight at a time: all loads of a batch are issued before the first is used (the list of an
         // entry is a chain of dependent loads otherwise: column index -> d), the sum itself stays sequential (same bits)
@@ -113,13 +116,18 @@ __global__ __launch_bounds__(256) void adat_list_kernel(const int* __restrict__ 
         B[(int64_t)r * ldb + r] = 1.0;
     }
 }
+__global__ __launch_bounds__(256) void adat_list_kernel(const int* __restrict__ bptr, const int* __restrict__ bi,
+                                                        const int* __restrict__ bk, const int* __restrict__ bcol,
+                                                        const double* __restrict__ bai, const double* __restrict__ bak, int nb,
+                                                        const double* __restrict__ d, double* B, int64_t ldb, int m, int mp,
+                                                        const int* done) { adat_list_kernel_body(bptr, bi, bk, bcol, bai, bak, nb, d, B, ldb, m, mp, done, blockIdx.x, gridDim.x); }
 
 // Same contract with the accumulator row in HBM (mp too large for LDS): the owning workgroup zeroes
 // its row of B, then accumulates in place; __syncthreads() orders the read-modify-writes of one CU.
-__global__ __launch_bounds__(256) void adat_sparse_global_kernel(SparseA A, const double* __restrict__ d, double* B,
-                                                                 int64_t ldb, int mp, const int* done) {
+__device__ __forceinline__ void adat_sparse_global_kernel_body(SparseA A, const double* __restrict__ d, double* B,
+                                                                 int64_t ldb, int mp, const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = bx_, tid = threadIdx.x;
     double* out = B + (int64_t)row * ldb;
     for (int k = tid; k < mp; k += 256) out[k] = (row >= A.m && k == row) ? 1.0 : 0.0;
     __syncthreads();
@@ -133,15 +141,17 @@ __global__ __launch_bounds__(256) void adat_sparse_global_kernel(SparseA A, cons
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void adat_sparse_global_kernel(SparseA A, const double* __restrict__ d, double* B,
+                                                                 int64_t ldb, int mp, const int* done) { adat_sparse_global_kernel_body(A, d, B, ldb, mp, done, blockIdx.x, gridDim.x); }
 
 // out[i] = sa * (A[i,:] . v) + sb * add[i]  (CSR; 16 lanes per row, fixed-order tree reduction);
 // rows m..mp-1 (padding) get sb * add[i].
-__global__ __launch_bounds__(256) void spmv_csr_kernel(SparseA A, int mp, const double* __restrict__ v, double sa,
+__device__ __forceinline__ void spmv_csr_kernel_body(SparseA A, int mp, const double* __restrict__ v, double sa,
                                                        double sb, const double* __restrict__ add, double* out,
-                                                       const int* done) {
+                                                       const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
     const int l16 = threadIdx.x & 15;
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int row = bx_ * 16 + (threadIdx.x >> 4);
     if (row >= mp) return;
     double s = 0.0;
     if (row < A.m) {
@@ -154,14 +164,17 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(SparseA A, int mp, const 
     s += __shfl_xor(s, 1, 16);
     if (l16 == 0) out[row] = sa * s + (add ? sb * add[row] : 0.0);
 }
+__global__ __launch_bounds__(256) void spmv_csr_kernel(SparseA A, int mp, const double* __restrict__ v, double sa,
+                                                       double sb, const double* __restrict__ add, double* out,
+                                                       const int* done) { spmv_csr_kernel_body(A, mp, v, sa, sb, add, out, done, blockIdx.x, gridDim.x); }
 
 // w[j] = A[:,j] . u  (CSC; 16 lanes per column).  Written to w[0..np): the vector kernels read it as
 // the single "row chunk" of the dense GEMV-T partial buffer.
-__global__ __launch_bounds__(256) void spmv_csc_t_kernel(SparseA A, int np, const double* __restrict__ u, double* w,
-                                                         const int* done) {
+__device__ __forceinline__ void spmv_csc_t_kernel_body(SparseA A, int np, const double* __restrict__ u, double* w,
+                                                         const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
     const int l16 = threadIdx.x & 15;
-    const int col = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int col = bx_ * 16 + (threadIdx.x >> 4);
     if (col >= np) return;
     double s = 0.0;
     if (col < A.n) {
@@ -174,5 +187,7 @@ __global__ __launch_bounds__(256) void spmv_csc_t_kernel(SparseA A, int np, cons
     s += __shfl_xor(s, 1, 16);
     if (l16 == 0) w[col] = s;
 }
+__global__ __launch_bounds__(256) void spmv_csc_t_kernel(SparseA A, int np, const double* __restrict__ u, double* w,
+                                                         const int* done) { spmv_csc_t_kernel_body(A, np, u, w, done, blockIdx.x, gridDim.x); }
 
 }  // namespace ipm

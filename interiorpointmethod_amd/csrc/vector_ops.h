@@ -160,9 +160,9 @@ __device__ __forceinline__ double col_sum(const double* atp, int rc_chunks, int 
 }
 
 // r_c = A^T y + s - c ; d = x/s ; predictor v = d*(r_c - r3/x) ; partial ||r_c||^2, x.s, c.x, ||r_b||^2
-__global__ __launch_bounds__(VBLK) void prepare_kernel(VecArgs a) {
+__device__ __forceinline__ void prepare_kernel_body(VecArgs a, const unsigned bx_, const unsigned gx_) {
     __shared__ double red[VBLK];
-    const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
+    const int gid = bx_ * VBLK + threadIdx.x, gsz = gx_ * VBLK;
     double rc2 = 0.0, xs = 0.0, cx = 0.0, rb2 = 0.0;
     for (int j = gid; j < a.n; j += gsz) {
         double xj = a.x[j], sj = a.s[j];
@@ -180,12 +180,13 @@ __global__ __launch_bounds__(VBLK) void prepare_kernel(VecArgs a) {
     for (int i = gid; i < a.m; i += gsz) { double r = a.rb[i]; rb2 += r * r; }
     rc2 = block_sum(rc2, red); xs = block_sum(xs, red); cx = block_sum(cx, red); rb2 = block_sum(rb2, red);
     if (threadIdx.x == 0) {
-        a.part[P_RC2 * MAXPART + blockIdx.x] = rc2;
-        a.part[P_XS * MAXPART + blockIdx.x] = xs;
-        a.part[P_CX * MAXPART + blockIdx.x] = cx;
-        a.part[P_RB2 * MAXPART + blockIdx.x] = rb2;
+        a.part[P_RC2 * MAXPART + bx_] = rc2;
+        a.part[P_XS * MAXPART + bx_] = xs;
+        a.part[P_CX * MAXPART + bx_] = cx;
+        a.part[P_RB2 * MAXPART + bx_] = rb2;
     }
 }
+__global__ __launch_bounds__(VBLK) void prepare_kernel(VecArgs a) { prepare_kernel_body(a, blockIdx.x, gridDim.x); }
 
 // d = x / s only (main.py:223): what the formation of A D^2 A^T needs; the full prepare_kernel follows on the residual
 // stream while the factorization runs (ipm_api.hip, enqueue_iteration)
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(VBLK) void scaling_kernel(VecArgs a) {
 }
 
 // stop test of check_optimality (main.py:162-173) -- one thread.
-__global__ void stop_test_kernel(VecArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void stop_test_kernel_body(VecArgs a, const unsigned bx_, const unsigned gx_) {
+    if (threadIdx.x != 0 || bx_ != 0) return;
     Scalars* sc = a.sc;
     if (sc->done) return;
     double rb = sqrt(sum_partials(a.part, P_RB2, a.nblk));
@@ -221,13 +222,14 @@ __global__ void stop_test_kernel(VecArgs a) {
         sc->done = 1;
     }
 }
+__global__ void stop_test_kernel(VecArgs a) { stop_test_kernel_body(a, blockIdx.x, gridDim.x); }
 
 // direction recovery + ratio test.  corr == 0: (dxa, dsa) from dya with q = r3/x;
 // corr == 1: (dx, ds) from dy with the corrector q.
-__global__ __launch_bounds__(VBLK) void direction_kernel(VecArgs a, int corr) {
+__device__ __forceinline__ void direction_kernel_body(VecArgs a, int corr, const unsigned bx_, const unsigned gx_) {
     if (a.sc->done) return;
     __shared__ double red[VBLK];
-    const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
+    const int gid = bx_ * VBLK + threadIdx.x, gsz = gx_ * VBLK;
     double* DX = corr ? a.dx : a.dxa;
     double* DS = corr ? a.ds : a.dsa;
     double mp_ = 1.0, md_ = 1.0;
@@ -242,31 +244,33 @@ __global__ __launch_bounds__(VBLK) void direction_kernel(VecArgs a, int corr) {
     }
     mp_ = block_min(mp_, red); md_ = block_min(md_, red);
     if (threadIdx.x == 0) {
-        a.part[(corr ? P_MINP : P_MINP_AFF) * MAXPART + blockIdx.x] = mp_;
-        a.part[(corr ? P_MIND : P_MIND_AFF) * MAXPART + blockIdx.x] = md_;
+        a.part[(corr ? P_MINP : P_MINP_AFF) * MAXPART + bx_] = mp_;
+        a.part[(corr ? P_MIND : P_MIND_AFF) * MAXPART + bx_] = md_;
     }
 }
+__global__ __launch_bounds__(VBLK) void direction_kernel(VecArgs a, int corr) { direction_kernel_body(a, corr, blockIdx.x, gridDim.x); }
 
 // partial sums of (x + a_p dxa).(s + a_d dsa)      main.py:579-584, 598
-__global__ __launch_bounds__(VBLK) void mu_aff_kernel(VecArgs a) {
+__device__ __forceinline__ void mu_aff_kernel_body(VecArgs a, const unsigned bx_, const unsigned gx_) {
     if (a.sc->done) return;
     __shared__ double red[VBLK];
-    const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
+    const int gid = bx_ * VBLK + threadIdx.x, gsz = gx_ * VBLK;
     const double ap = min_partials(a.part, P_MINP_AFF, a.nblk);
     const double ad = min_partials(a.part, P_MIND_AFF, a.nblk);
     double acc = 0.0;
     for (int j = gid; j < a.n; j += gsz) acc += (a.x[j] + ap * a.dxa[j]) * (a.s[j] + ad * a.dsa[j]);
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) {
-        a.part[P_MUAFF * MAXPART + blockIdx.x] = acc;
-        if (blockIdx.x == 0) { a.sc->alpha_aff_p = ap; a.sc->alpha_aff_d = ad; }
+        a.part[P_MUAFF * MAXPART + bx_] = acc;
+        if (bx_ == 0) { a.sc->alpha_aff_p = ap; a.sc->alpha_aff_d = ad; }
     }
 }
+__global__ __launch_bounds__(VBLK) void mu_aff_kernel(VecArgs a) { mu_aff_kernel_body(a, blockIdx.x, gridDim.x); }
 
 // corrector: r3c = x s + dxa dsa - sigma mu ; q = r3c/x ; v = d (r_c - q)     main.py:150-152
-__global__ __launch_bounds__(VBLK) void corrector_rhs_kernel(VecArgs a) {
+__device__ __forceinline__ void corrector_rhs_kernel_body(VecArgs a, const unsigned bx_, const unsigned gx_) {
     if (a.sc->done) return;
-    const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
+    const int gid = bx_ * VBLK + threadIdx.x, gsz = gx_ * VBLK;
     const double mu = a.sc->mu;
     const double mu_aff = sum_partials(a.part, P_MUAFF, a.nblk) / (double)a.n;
     const double r = mu_aff / mu;
@@ -281,11 +285,12 @@ __global__ __launch_bounds__(VBLK) void corrector_rhs_kernel(VecArgs a) {
     }
     if (gid == 0) { a.sc->mu_aff = mu_aff; a.sc->sigma = sigma; }
 }
+__global__ __launch_bounds__(VBLK) void corrector_rhs_kernel(VecArgs a) { corrector_rhs_kernel_body(a, blockIdx.x, gridDim.x); }
 
 // x += a_p dx ; y += a_d dy ; s += a_d ds ; k += 1          main.py:604-626, 694-696
-__global__ __launch_bounds__(VBLK) void update_kernel(VecArgs a) {
+__device__ __forceinline__ void update_kernel_body(VecArgs a, const unsigned bx_, const unsigned gx_) {
     if (a.sc->done) return;
-    const int gid = blockIdx.x * VBLK + threadIdx.x, gsz = gridDim.x * VBLK;
+    const int gid = bx_ * VBLK + threadIdx.x, gsz = gx_ * VBLK;
     const double eta = a.sc->eta;
     const double ap = fmin(1.0, eta * min_partials(a.part, P_MINP, a.nblk));
     const double ad = fmin(1.0, eta * min_partials(a.part, P_MIND, a.nblk));
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(VBLK) void update_kernel(VecArgs a) {
         sc->alpha_p = ap; sc->alpha_d = ad; sc->k = k + 1;
     }
 }
+__global__ __launch_bounds__(VBLK) void update_kernel(VecArgs a) { update_kernel_body(a, blockIdx.x, gridDim.x); }
 
 // out[i] = value for i < n (fill)
 __global__ void fill_kernel(double* out, int n, double value) {

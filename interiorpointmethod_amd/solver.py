@@ -239,7 +239,7 @@ class IpmSolver:
 
     def __init__(self, A, b, c, device=0, eta=0.91, pivot_guard_eps=1e-30, pivot_guard_big=1e64,
                  check_every=4, use_torch=True, dense=False, regularize=0.0, reorder="auto", concurrent=False,
-                 auto_regularize=True, factor=None, prepared=None):
+                 auto_regularize=True, factor=None, prepared=None, lockstep=False):
         lib = _lib.load()
         self._lib = lib
         self._h = None
@@ -262,7 +262,9 @@ class IpmSolver:
         # concurrent=True: this handle shares the GPU with others (batched mode) -- one stream per handle, no look-ahead, no
         # device polling (include/ipm_hip.h: IPM_FLAG_SINGLE_STREAM).  Without it the library still protects itself (it
         # counts the live handles per device and falls back to stream events).
-        opts.flags = ((_lib.FLAG_NO_DEVICE_POLLING | _lib.FLAG_SINGLE_STREAM) if concurrent else 0) | \
+        # lockstep=True: the handle is meant for solve_lockstep (ipm_solve_batch: iteration k of several LPs in the same launches)
+        opts.flags = (_lib.FLAG_LOCKSTEP if lockstep else 0) | \
+                     ((_lib.FLAG_NO_DEVICE_POLLING | _lib.FLAG_SINGLE_STREAM) if concurrent else 0) | \
                      (0 if auto_regularize else _lib.FLAG_NO_AUTO_REGULARIZE) | \
                      (_lib.FLAG_SPARSE_FACTOR if self.factor == "sparse" else 0)
         nbytes = C.c_size_t(0)
@@ -464,6 +466,28 @@ class IpmSolver:
         nfix = C.c_int32(0)
         self._check(self._lib.ipm_solve_linear(self._h, _dptr(B), self.m, _dptr(rhs), _dptr(z), C.byref(nfix)))
         return z.reshape(-1, 1), nfix.value
+
+
+def solve_lockstep(solvers, tol=1e-8, max_iter=5000, tol_gap=None):
+    """ipm_solve_batch: solve the LPs of `solvers` (IpmSolver objects created with lockstep=True on one device, a state set) AT ONCE,
+    iteration k of all of them in the same launches (csrc/lockstep.h) -> list of statistics dicts, one per solver.  Per-LP semantics
+    and arithmetic are those of IpmSolver.solve on each of them alone (bit-identical iterates)."""
+    lib = _lib.load()
+    n = len(solvers)
+    hs = (C.c_void_p * n)(*[sv._h for sv in solvers])
+    st = (_lib.Stats * n)()
+    _lib.check(solvers[0]._h, lib.ipm_solve_batch(hs, n, tol, tol, tol if tol_gap is None else tol_gap, int(max_iter), st))
+    out = []
+    for sv, s_ in zip(solvers, st):
+        sv.stats = s_.as_dict()
+        out.append(sv.stats)
+    return out
+
+
+def lockstep_eligible(solver):
+    """Can this IpmSolver join solve_lockstep?  Sparse A on the dense-tile factor, more than 128 rows (the small LPs have their fused
+    single-workgroup kernel, the sparse-factor LPs their tree sweeps)."""
+    return bool(solver.sparse and solver.factor != "sparse" and not solver.schedule()["fused_small"])
 
 
 def _info(solver, cTlb=0.0):

@@ -1,0 +1,89 @@
+"""GPU tests (-m gpu) of the LOCKSTEP BATCH (csrc/lockstep.h, ipm_solve_batch): iteration k of several independent LPs in the same
+launches -- the driver loop of the reference (script.py:147-173 over the Netlib files) as one chain of launches instead of one
+chain per LP.  A handle's arithmetic in the batch is the body of the very kernels it would launch alone, with the same arguments
+in the same order, so every LP of a batch must end BIT-IDENTICAL to the same handle solved alone with ipm_solve: status,
+iteration count, objective, residuals, (x, y, s).  fp64; bit-exact asserts."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import interiorpointmethod_amd as ipm                              # noqa: E402
+from interiorpointmethod_amd.matio import load_npz_problem         # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "netlib")
+
+
+def _load(nm):
+    A, b, c, _, valid = load_npz_problem(os.path.join(GOLDEN, nm + ".npz"))
+    assert valid
+    return A, b, c
+
+
+def _alone(A, b, c, max_iter):
+    with ipm.IpmSolver(A, b, c, lockstep=True, factor="dense") as sv:
+        sv.init_state(1.0)
+        st = sv.solve(tol=1e-8, max_iter=max_iter)
+        return st, sv.get_state()
+
+
+@pytest.mark.parametrize("names,max_iter", [
+    (["BANDM", "SCFXM1", "E226", "SC205"], 300),                              # 2-3 blocks, product-list formation
+    (["DEGEN3", "BNL1", "WOODW", "25FV47", "SEBA", "BANDM"], 120),           # 3 ... 12 blocks, with and without a tile envelope
+    (["BNL2", "MAROS-R7", "TRUSS", "SCSD8", "D2Q06C"], 60),                  # envelope LPs, rows above 1536 (row-owner formation)
+])
+def test_lockstep_batch_is_bit_identical_to_one_at_a_time(names, max_iter):
+    probs = [_load(nm) for nm in names]
+    ref = [_alone(*p, max_iter) for p in probs]
+    svs = [ipm.IpmSolver(*p, lockstep=True, factor="dense") for p in probs]
+    try:
+        for sv in svs:
+            assert ipm.lockstep_eligible(sv)
+            sv.init_state(1.0)
+        stats = ipm.solve_lockstep(svs, tol=1e-8, max_iter=max_iter)
+        for nm, sv, st, (st0, (x0, y0, s0)) in zip(names, svs, stats, ref):
+            x, y, s = sv.get_state()
+            assert st["status"] == st0["status"] and st["iterations"] == st0["iterations"], (nm, st, st0)
+            for k in ("objective", "rp_norm", "rd_norm", "gap", "pivots_fixed", "auto_regularized"):
+                assert st[k] == st0[k] or (np.isnan(st[k]) and np.isnan(st0[k])), (nm, k, st[k], st0[k])
+            assert np.array_equal(x, x0, equal_nan=True) and np.array_equal(y, y0, equal_nan=True) and np.array_equal(s, s0, equal_nan=True), nm
+    finally:
+        for sv in svs:
+            sv.close()
+
+
+def test_lockstep_batch_restarts_a_rank_deficient_lp_with_the_automatic_shift():
+    """QAP8 has 13 % dependent rows: ipm_solve switches the 1e-14 Tikhonov shift on after the first factorization and restarts; in
+    a batch that restart must touch only that LP (its program is re-recorded), the neighbours run on."""
+    names = ["QAP8", "BANDM", "SCFXM1"]
+    probs = [_load(nm) for nm in names]
+    ref = [_alone(*p, 100) for p in probs]
+    assert ref[0][0]["auto_regularized"] == 1 and ref[0][0]["status"] == 1
+    svs = [ipm.IpmSolver(*p, lockstep=True, factor="dense") for p in probs]
+    try:
+        for sv in svs:
+            sv.init_state(1.0)
+        stats = ipm.solve_lockstep(svs, tol=1e-8, max_iter=100)
+        for nm, sv, st, (st0, (x0, y0, s0)) in zip(names, svs, stats, ref):
+            x, y, s = sv.get_state()
+            assert (st["status"], st["iterations"], st["auto_regularized"]) == (st0["status"], st0["iterations"], st0["auto_regularized"]), nm
+            assert st["objective"] == st0["objective"] and np.array_equal(x, x0) and np.array_equal(y, y0), nm
+    finally:
+        for sv in svs:
+            sv.close()
+
+
+def test_lockstep_rejects_handles_it_cannot_serve():
+    A, b, c = _load("AFIRO")                                   # 27 rows: the fused single-workgroup kernel serves it
+    with ipm.IpmSolver(A, b, c, lockstep=True) as sv:
+        sv.init_state(1.0)
+        assert not ipm.lockstep_eligible(sv)
+        with pytest.raises(ipm.IpmError):
+            ipm.solve_lockstep([sv])
+    A, b, c = _load("BANDM")
+    with ipm.IpmSolver(A, b, c) as sv:                          # not created for the batch
+        sv.init_state(1.0)
+        with pytest.raises(ipm.IpmError):
+            ipm.solve_lockstep([sv])

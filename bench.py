@@ -417,7 +417,7 @@ def cpu_baseline_subset(cb, subset):
 
 
 def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, workers=2, schedule="dynamic",
-               start="reference", regularize=0.0, general=False):
+               start="reference", regularize=0.0, general=False, lockstep=True):
     """Timed batched solve of the set -> (records, elapsed seconds incl. the gather, max over ranks)."""
     import torch
     from interiorpointmethod_amd import batch
@@ -435,6 +435,7 @@ def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, 
                              collective_at_world_one=bool(os.environ.get("IPM_BENCH_FORCE_DIST")),
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
                              tol=1e-8, regularize=regularize, workers=workers, schedule=schedule, start=start,
+                             lockstep=(lockstep and start == "reference" and os.environ.get("IPM_LOCKSTEP", "1") != "0"),
                              # the general-form driver's own settings: e3 = 1e-6, at most 999 iterations (main.py:1088-1127)
                              **(dict(max_iter=999, tol_gap=1e-6) if general else dict(max_iter=300)))
     torch.cuda.synchronize()
@@ -480,8 +481,11 @@ def netlib_main(args):
                "value": summ["converged"] / elapsed, "unit": "LPs/s", "n_gpus": max(world, 1), "steps": len(names),
                "warmup": 1, "ms_per_step": 1e3 * elapsed / max(len(names), 1), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "netlib fixtures (tests/golden/netlib)",
-               "config": {"workload": "Netlib %s set, %d LPs over %d GPU(s), %s; per GPU %d LP(s) in flight on separate streams" % (
-                   args.netlib_set, len(names), max(world, 1), sched, max(1, args.workers))},
+               "config": {"workload": "Netlib %s set, %d LPs over %d GPU(s), %s; per GPU %s" % (
+                   args.netlib_set, len(names), max(world, 1), sched,
+                   "lockstep batches by size class (iteration k of the LPs of a class in the same launches), %d set-up threads" % max(1, args.workers)
+                   if (args.start == "reference" and os.environ.get("IPM_LOCKSTEP", "1") != "0" and args.workers > 1)
+                   else "%d LP(s) in flight on separate streams" % max(1, args.workers))},
                "roofline": netlib_roofline(names, probs, flops, rec, elapsed, world),
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize, "start_point": args.start,
                "per_lp": per_lp_table(names, rec)}
@@ -687,7 +691,7 @@ def main():
                     names, probs, flops = [names[i] for i in keep], [probs[i] for i in keep], [flops[i] for i in keep]
                 rec, el = run_netlib(names, probs, flops, dev, workers=8)
                 summ = batch.summarize(rec)
-                out[key] = {"metric": "Netlib LPs/sec (%s, tol=1e-8, cap 300, 8 LPs in flight)" % label,
+                out[key] = {"metric": "Netlib LPs/sec (%s, tol=1e-8, cap 300, lockstep batches by size class)" % label,
                             "value": summ["converged"] / el, "unit": "LPs/s", "n_gpus": 1, "wall_seconds": el,
                             "summary": summ, "roofline": netlib_roofline(names, probs, flops, rec, el, 1),
                             "per_lp": per_lp_table(names, rec)}

@@ -200,6 +200,20 @@ int ipm_solve(ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t
  * Tikhonov shift); stats[i] (may be NULL) describes handle i, with solve_ms the device time of the whole batch.  The arithmetic
  * of a handle is exactly that of ipm_solve on it alone: bit-identical iterates.  Launched on the first handle's stream. */
 int ipm_solve_batch(ipm_handle** handles, int32_t n, double tol_p, double tol_d, double tol_gap, int32_t max_iter, ipm_stats* stats);
+/* The same batch, incrementally: handles may JOIN between two steps (a host thread finishes an LP's set-up while the batch is already
+ * running) and the caller learns which ones finished after every step (and can tear them down while the batch runs on).
+ * ipm_batch_add: the handle (requirements as above) starts its solve from its current state, *index = its position in the batch.
+ * ipm_batch_step: opt.check_every iterations of every active handle in lockstep; the indices of the handles that finished in this
+ * step go to finished[0 .. *n_finished), *n_active = handles still running (0: nothing left to do).  ipm_batch_stats: the statistics
+ * of a finished handle.  A batch owns one stream; it is not thread-safe; the handles stay owned by the caller and must outlive their
+ * part in the batch (destroy a handle only after ipm_batch_step reported it finished, or after ipm_batch_destroy). */
+typedef struct ipm_batch ipm_batch;
+int ipm_batch_create(int device, ipm_batch** out);
+int ipm_batch_destroy(ipm_batch* b);
+const char* ipm_batch_last_error(const ipm_batch* b);
+int ipm_batch_add(ipm_batch* b, ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t max_iter, int32_t* index);
+int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int32_t* n_finished, int32_t* n_active);
+int ipm_batch_stats(ipm_batch* b, int32_t index, ipm_stats* stats);
 /* Per-iteration records of the last ipm_solve / ipm_iterate, oldest first: min(iterations, IPM_HISTORY_CAPACITY,
  * capacity) records are written to `out` (host) and their number to *count. */
 int ipm_get_history(ipm_handle* h, ipm_iter_record* out, int32_t capacity, int32_t* count);

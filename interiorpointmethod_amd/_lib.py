@@ -18,7 +18,7 @@ EXPORTS = [
     "ipm_abi_version", "ipm_device_count", "ipm_default_options", "ipm_workspace_bytes", "ipm_workspace_bytes_csc", "ipm_workspace_bytes_opts",
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
-    "ipm_iterate", "ipm_solve", "ipm_solve_batch", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
+    "ipm_iterate", "ipm_solve", "ipm_solve_batch", "ipm_batch_create", "ipm_batch_destroy", "ipm_batch_last_error", "ipm_batch_add", "ipm_batch_step", "ipm_batch_stats", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
     "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps", "ipm_debug_ff_schedule", "ipm_debug_ff_trace", "ipm_debug_get_block_inverse",
 ]
 
@@ -123,6 +123,13 @@ def load():
     lib.ipm_iterate.argtypes = [vp, i32, C.POINTER(Stats)]
     lib.ipm_solve.argtypes = [vp, dbl, dbl, dbl, i32, C.POINTER(Stats)]
     lib.ipm_solve_batch.argtypes = [C.POINTER(vp), i32, dbl, dbl, dbl, i32, C.POINTER(Stats)]
+    lib.ipm_batch_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.ipm_batch_destroy.argtypes = [vp]
+    lib.ipm_batch_last_error.argtypes = [vp]
+    lib.ipm_batch_last_error.restype = C.c_char_p
+    lib.ipm_batch_add.argtypes = [vp, vp, dbl, dbl, dbl, i32, C.POINTER(i32)]
+    lib.ipm_batch_step.argtypes = [vp, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.ipm_batch_stats.argtypes = [vp, i32, C.POINTER(Stats)]
     lib.ipm_get_history.argtypes = [vp, C.POINTER(IterRecord), i32, C.POINTER(i32)]
     lib.ipm_get_schedule.argtypes = [vp, C.POINTER(i32)]
     lib.ipm_order_rows.argtypes = [i64, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), pd]
@@ -139,7 +146,7 @@ def load():
     lib.ipm_debug_ff_trace.argtypes = [vp, C.POINTER(C.c_longlong), i64, C.POINTER(i64), C.POINTER(C.c_ubyte), C.POINTER(i32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("ipm_default_options", "ipm_last_error"):
+        if name not in ("ipm_default_options", "ipm_last_error", "ipm_batch_last_error"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -152,6 +152,179 @@ def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
     return rec
 
 
+LOCKSTEP_MAX_ROWS = int(__import__("os").environ.get("IPM_LOCKSTEP_MAX_ROWS", 1 << 30))
+# host threads (= streams) that solve the LPs outside the batches (up to 128 rows, sparse factor) one after the other: with one
+# stream per batch and these, the rank uses about as many streams as the GPU has hardware queues
+LOCKSTEP_CLASSIC_THREADS = int(__import__("os").environ.get("IPM_LOCKSTEP_CLASSIC_THREADS", 2))
+# row limits of the size classes of the lockstep batches (one batch per class; the last class is open ended)
+LOCKSTEP_CLASSES = [int(v) for v in __import__("os").environ.get("IPM_LOCKSTEP_CLASSES", "1100,2200").split(",") if v]
+
+
+def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, tol_gap=None, **_):
+    """Solve problems[i] for i in ids on this rank's GPU with the LOCKSTEP BATCH -> (len(ids), NF) records.
+
+    `workers` host threads prepare the LPs (host analysis, handle, upload), largest first.  LPs the batch cannot serve -- up to 128
+    rows (fused single-workgroup kernel) and the ones `factor="auto"` puts on the sparse multifrontal factor -- are solved by their
+    thread right away, each on a stream of its own, as in solve_shard.  Every other LP JOINS the one running batch as soon as its
+    handle is ready (ipm_batch_add between two steps): iteration k of all of them in the same launches (csrc/lockstep.h), so that
+    the rank's chain of launches is that of its longest LP instead of eight chains that share four hardware queues.  Finished LPs
+    are read back and destroyed by the pool while the batch runs on.  Per-LP results are those of a one-at-a-time solve of the
+    same handle, bit for bit (tests/test_gpu_lockstep.py)."""
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _lib
+    from .solver import IpmSolver, LockstepBatch, _info, lockstep_eligible, prepare
+    rec = np.zeros((len(ids), NF), dtype=np.float64)
+    import threading
+    classic_q = queue.Queue()
+
+    def classic(problem, device=0, prepared=None):
+        from .solver import solve_with_info
+        A, b, c = problem
+        _, _, _, info = solve_with_info(A, b, c, tol=tol, max_iter=max_iter, y0=y0, device=device, regularize=regularize,
+                                        concurrent=True, tol_gap=tol_gap, prepared=prepared)
+        return dict(info)
+
+    def wants_lockstep(i):
+        return 128 < problems[i][0].shape[0] <= LOCKSTEP_MAX_ROWS
+
+    def one(row_i, ready):          # ready: queue of (row, lp id, solver, setup seconds) | None = a setup task ended without a handle
+        row, i = row_i
+        A, b, c = problems[i]
+        t0 = time.perf_counter()
+        sv, handed = None, False
+        try:
+            prepared = prepare(A, b, c)                     # host analysis ONCE: row order, factor path
+            if wants_lockstep(i) and prepared.factor != "sparse":
+                sv = IpmSolver(A, b, c, device=device, regularize=regularize, lockstep=True, concurrent=True, prepared=prepared)
+                if lockstep_eligible(sv):
+                    sv.init_state(y0)
+                    ready.put((row, i, sv, time.perf_counter() - t0))
+                    handed = True
+                    return
+                sv.close()
+                sv = None
+            classic_q.put((row, i, prepared, t0))         # solved by a classic runner thread (few streams: see LOCKSTEP_CLASSIC_THREADS)
+            return
+        except Exception as e:          # every failure becomes a record: the rank must still reach the all-gather
+            import sys
+            print("[batch] %d x %d LP failed: %s: %s" % (A.shape[0], A.shape[1], type(e).__name__, e), file=sys.stderr, flush=True)
+            if sv is not None:
+                sv.close()
+            info = _error_info(STATUS_INVALID_INPUT if getattr(e, "code", None) == _lib.ERR_INVALID_INPUT else STATUS_ERROR)
+        finally:
+            if wants_lockstep(i) and not handed:
+                ready.put(None)
+        info.setdefault("seconds", time.perf_counter() - t0)
+        rec[row] = _row(i, info)
+
+    def classic_runner():
+        while True:
+            item = classic_q.get()
+            if item is None:
+                return
+            row, i, prepared, t0 = item
+            try:
+                info = _in_own_stream(classic, problems[i], device, dict(prepared=prepared))
+            except Exception as e:
+                import sys
+                A = problems[i][0]
+                print("[batch] %d x %d LP failed: %s: %s" % (A.shape[0], A.shape[1], type(e).__name__, e), file=sys.stderr, flush=True)
+                info = _error_info(STATUS_INVALID_INPUT if getattr(e, "code", None) == _lib.ERR_INVALID_INPUT else STATUS_ERROR)
+            info.setdefault("seconds", time.perf_counter() - t0)
+            rec[row] = _row(i, info)
+
+    def finish(item, t_join, t_done):
+        row, i, sv, setup_s = item
+        t3 = time.perf_counter()
+        try:
+            info = _info(sv)
+            info["timeouts_recovered"] = sv.schedule()["timeouts_recovered"]
+            info["serial_launches"] = 0
+        except Exception:
+            info = _error_info()
+        sv.close()
+        info["setup_seconds"], info["solve_seconds"], info["teardown_seconds"] = setup_s, t_done - t_join, time.perf_counter() - t3
+        info["seconds"] = setup_s + (t_done - t_join)
+        rec[row] = _row(i, info)
+
+    # Size classes: ONE batch per class, each on a stream of its own, run from a host thread of its own.  In a batch every global step
+    # lasts as long as its slowest LP's kernel, so LPs of very different size in one batch inflate each other's chain (measured: all 53
+    # LPs in one batch run 5.4 ms per iteration where the largest alone needs 2.5); a class of similar LPs keeps the chain at its leader's.
+    def cls_of(i):
+        m = problems[i][0].shape[0]
+        for k, lim in enumerate(LOCKSTEP_CLASSES):
+            if m <= lim:
+                return k
+        return len(LOCKSTEP_CLASSES)
+    ncls = len(LOCKSTEP_CLASSES) + 1
+    ready = [queue.Queue() for _ in range(ncls)]
+
+    def one_cls(row_i):
+        k = cls_of(row_i[1])
+        one(row_i, ready[k])
+
+    # the lockstep candidates first (largest first: a batch should start with its longest chains), then the rest
+    rows = sorted(enumerate(ids), key=lambda r: (not wants_lockstep(r[1]), -problems[r[1]][0].shape[0], r[1]))
+    expected = [0] * ncls
+    for r in rows:
+        if wants_lockstep(r[1]):
+            expected[cls_of(r[1])] += 1
+    pool = ThreadPoolExecutor(max_workers=max(1, workers))
+    futs = [pool.submit(one_cls, r) for r in rows]
+    tails, tails_lock = [], threading.Lock()
+
+    def run_class(k):
+        arrived, joined = 0, {}
+        if expected[k] == 0:
+            return
+        try:
+            with LockstepBatch(device=device, tol=tol, max_iter=max_iter, tol_gap=tol_gap) as lb:
+                while arrived < expected[k] or lb.active > 0:
+                    # every handle that is ready joins now; with nothing running, wait for the next one
+                    while arrived < expected[k]:
+                        try:
+                            item = ready[k].get(block=(lb.active == 0))
+                        except queue.Empty:
+                            break
+                        arrived += 1
+                        if item is not None:
+                            joined[id(item[2])] = (item, time.perf_counter())
+                            lb.add(item[2])
+                    if lb.active == 0:
+                        continue
+                    done = lb.step()
+                    t_done = time.perf_counter()
+                    for sv in done:
+                        item, t_join = joined.pop(id(sv))
+                        with tails_lock:
+                            tails.append(pool.submit(finish, item, t_join, t_done))
+        except Exception as e:          # the handles still in the batch become error records: the rank must still reach the all-gather
+            import sys
+            print("[batch] lockstep batch failed: %s: %s" % (type(e).__name__, e), file=sys.stderr, flush=True)
+            for item, _t in joined.values():
+                rec[item[0]] = _row(item[1], dict(_error_info(), seconds=0.0))
+                try:
+                    item[2].close()
+                except Exception:
+                    pass
+
+    runners = [threading.Thread(target=run_class, args=(k,)) for k in range(ncls)]
+    crunners = [threading.Thread(target=classic_runner) for _ in range(max(1, LOCKSTEP_CLASSIC_THREADS))]
+    for t in runners + crunners:
+        t.start()
+    for f in futs:
+        f.result()                       # every LP is set up: the classic queue is complete
+    for _ in crunners:
+        classic_q.put(None)
+    for t in runners + crunners:
+        t.join()
+    for f in tails:
+        f.result()
+    pool.shutdown()
+    return rec
+
+
 def gather_records(local, shard_sizes, dist=None, device=None):
     """All ranks obtain all records, ordered by LP id.  One all_gather of (max_shard, NF) float64
     tensors (padded with id = -1); 8 NF = 112 B per LP, latency-bound, xGMI bandwidth irrelevant."""
@@ -242,7 +415,7 @@ def _gather_sparse(rec, dist, device=None):
 
 
 def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1,
-              schedule="static", store=None, collective_at_world_one=False, **kw):
+              schedule="static", store=None, collective_at_world_one=False, lockstep=False, **kw):
     """Shard `problems` (list of (A, b, c)) over the ranks of `dist`, solve, gather statistics.
 
     schedule="static": deterministic LPT partition on the predicted cost, no scheduling traffic at all.
@@ -260,7 +433,10 @@ def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, sol
     rank = dist.get_rank() if live else 0
     if costs is None:
         costs = [predicted_cost(p[0].shape[0], p[0].shape[1]) for p in problems]
-    store = store if (multi and schedule == "dynamic") else None
+    # lockstep=True: each rank solves its shard of the static partition with the lockstep batch (solve_shard_lockstep): the ranks'
+    # wall times are then set by their longest LP, which a pull-based schedule cannot improve
+    lockstep = bool(lockstep) and solve_fn is solve_one and workers > 1
+    store = store if (multi and schedule == "dynamic" and not lockstep) else None
     t0 = time.perf_counter()
     if store is not None:
         order = sorted(range(len(problems)), key=lambda i: (-float(costs[i]), i))
@@ -268,7 +444,10 @@ def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, sol
         seconds = time.perf_counter() - t0
         return _gather_sparse(local, dist, device=gather_device), seconds
     shards = lpt_partition(costs, world)
-    local = solve_shard(problems, shards[rank], device=device, solve_fn=solve_fn, workers=workers, **kw)
+    if lockstep:
+        local = solve_shard_lockstep(problems, shards[rank], device=device, workers=workers, **{k: v for k, v in kw.items() if k != "start"})
+    else:
+        local = solve_shard(problems, shards[rank], device=device, solve_fn=solve_fn, workers=workers, **kw)
     seconds = time.perf_counter() - t0
     records = gather_records(local, [len(s) for s in shards], dist=dist if multi else None,
                              device=gather_device)

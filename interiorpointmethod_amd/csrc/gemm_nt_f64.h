@@ -373,7 +373,7 @@ inline hipError_t launch_gemm_nt(GemmNT g, hipStream_t stream, double* slab = nu
             }
         }
     }
-    if (g_gemm_recorder && !g.w && !g.slab && g.batch == 1 && g.batch2 == 1) { g_gemm_recorder->fn(g_gemm_recorder->ctx, BM, BN, BK, WAVES_M, WAVES_N, g, grid); return hipSuccess; }
+    if (g_gemm_recorder && !g.w && !g.slab) { g_gemm_recorder->fn(g_gemm_recorder->ctx, BM, BN, BK, WAVES_M, WAVES_N, g, grid); return hipSuccess; }
     if (g.w)
         hipLaunchKernelGGL((gemm_nt_f64_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), dim3(grid, g.batch, g.batch2),
                            dim3(64 * WAVES_M * WAVES_N), 0, stream, g);

@@ -481,7 +481,8 @@ extern "C" int ipm_create(int device, int64_t m, int64_t n, const ipm_options* o
     if (h->opt.flags & IPM_FLAG_LOCKSTEP) { h->lockstep = 1; h->opt.flags |= IPM_FLAG_SINGLE_STREAM | IPM_FLAG_NO_DEVICE_POLLING; }
     if (h->opt.flags & IPM_FLAG_SINGLE_STREAM) h->lookahead = 0;
     if (const char* e = getenv("IPM_GROUPED_TRSV")) h->grouped_trsv = atoi(e);
-    if (h->lockstep) h->grouped_trsv = 0;      // block-step substitutions: every launch of the iteration has a lockstep twin (lockstep.h)
+    if (h->lockstep && getenv("IPM_LS_BLOCK_STEPS")) h->grouped_trsv = 0;      // (A/B: block-step substitutions in the lockstep batch)
+    if (h->lockstep) h->ss_small_blocks = 1 << 20;      // ONE panel / update kernel shape at every step: step k of all LPs of a batch then shares its launches
     if (h->no_dense) h->grouped_trsv = 0;      // the sparse factor has its own sweeps; a dense entry point on such a handle solves block by block
     h->gsz = 0;
     if (h->grouped_trsv) {
@@ -1814,7 +1815,8 @@ static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStr
     const int nG = g1 - g0;                               // groups [g0, g1)
     if (nG <= 0) return IPM_OK;
     const int* done = &h->sc->done;
-    hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, nG * GS), dim3(32, 8), 0, st, h->invD, h->gXT, h->gX, g0 * GS, GS, done);
+    if (!ls_push(h, LS_GROUP_DIAG_T, 16u * (unsigned)(nG * GS), LsGroupDiagT{h->invD, h->gXT, h->gX, g0 * GS, GS, done}))
+        hipLaunchKernelGGL(group_diag_transpose_kernel, dim3(4, 4, nG * GS), dim3(32, 8), 0, st, h->invD, h->gXT, h->gX, g0 * GS, GS, done);
     const int64_t gXs = GR * GR, gL = GR * (h->mp + 1), gSs = (GR / 2) * (GR / 2);   // group strides in X/XT, L, S
     double* gXT = h->gXT + g0 * gXs; double* gX = h->gX + g0 * gXs; double* gS = h->gS + g0 * gSs;
     const double* Lg = h->B + g0 * gL;
@@ -1848,6 +1850,7 @@ static int enqueue_group_inverses(ipm_handle* h, int g0 = 0, int g1 = -1, hipStr
 
 static void launch_dense_gemv_n(ipm_handle* h, const double* A, int64_t lda, int rows, int cols, const double* v, double sa,
                                 double sb, const double* add, double* out) {
+    if (ls_push(h, LS_GEMV_N, (unsigned)((rows + 3) / 4), LsGemvN{A, lda, rows, cols, v, sa, sb, add, out, &h->sc->done})) return;
     hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream, A, lda, rows, cols, v, sa, sb,
                        add, out, &h->sc->done);
 }
@@ -1897,9 +1900,11 @@ static int enqueue_potrs_grouped(ipm_handle* h, double* r, double* out, hipEvent
         left -= c0;
         if (left > 0) {
             dim3 grid((unsigned)((left + 511) / 512), 16);
-            hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->B + (int64_t)g * GR * h->mp + c0, h->mp, GR / 16, left,
-                               out + (int64_t)g * GR, h->gPart, done);
-            hipLaunchKernelGGL(sub_partials_kernel, dim3((unsigned)((left + 255) / 256)), dim3(256), 0, h->stream, z + c0, h->gPart, left, 16, done);
+            if (!ls_push(h, LS_GEMV_T, grid.x * 16u, LsGemvT{h->B + (int64_t)g * GR * h->mp + c0, h->mp, GR / 16, left, out + (int64_t)g * GR, h->gPart, done, grid.x}))
+                hipLaunchKernelGGL(gemv_t_kernel, grid, dim3(256), 0, h->stream, h->B + (int64_t)g * GR * h->mp + c0, h->mp, GR / 16, left,
+                                   out + (int64_t)g * GR, h->gPart, done);
+            if (!ls_push(h, LS_SUB_PARTIALS, (unsigned)((left + 255) / 256), LsSubPart{z + c0, h->gPart, left, 16, done}))
+                hipLaunchKernelGGL(sub_partials_kernel, dim3((unsigned)((left + 255) / 256)), dim3(256), 0, h->stream, z + c0, h->gPart, left, 16, done);
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -2404,11 +2409,16 @@ static void ls_gemm_hook(void* ctx, int bm, int bn, int bk, int wm, int wn, cons
     else if (bm == 64 && bn == 128 && bk == 16) type = LS_GEMM_64_128_16;
     else if (bm == 128 && bn == 128 && bk == 16 && wm == 2 && wn == 2) type = LS_GEMM_128_128_16;
     else if (bm == 32 && bn == 32 && bk == 32) type = LS_GEMM_32_32_32;
+    if (g.batch > 1 || g.batch2 > 1) {                       // the group inverses' batched products: 3-D grid packed into the LP's block range
+        if (type != LS_GEMM_32_32_32) { h->ls_cut = true; return; }
+        ls_push(h, LS_GEMM_32_32_32_BATCHED, (unsigned)grid * (unsigned)g.batch * (unsigned)g.batch2, g);
+        return;
+    }
     if (type < 0 || g.wait_on || g.signal) { h->ls_cut = true; return; }      // not recordable: ls_record_program reports it
     ls_push(h, type, (unsigned)grid, g);
 }
 static bool ls_eligible(const ipm_handle* h) {
-    return h->lockstep && h->sparse && !h->small && !h->spf && h->lookahead == 0 && h->stream2 == nullptr && !h->grouped_trsv && h->B && h->invD &&
+    return h->lockstep && h->sparse && !h->small && !h->spf && h->lookahead == 0 && h->stream2 == nullptr && h->B && h->invD &&
            h->haveA && h->haveBC && h->haveState;
 }
 // the launch sequence of ONE iteration of the handle, recorded (nothing is launched)
@@ -2425,7 +2435,7 @@ static int ls_record_program(ipm_handle* h, std::vector<LsLaunch>& prog) {
     if (cut || prog.empty()) return fail(h, IPM_ERR_STATE, "ipm_solve_batch: the handle's iteration holds a launch without a lockstep twin");
     return IPM_OK;
 }
-struct LsStep { int type; unsigned count, gridx, lds; size_t offset; };      // `count` records from `offset` on
+struct LsStep { int type; unsigned count, blocks, lds; size_t offset; };      // `count` records from `offset` on; blocks = sum of their grids
 // Merge the programs (each LP's order preserved) into global steps of one kernel type: the LP with the most launches left sets
 // the type of the next step, every LP whose next launch is of that type joins it.
 static void ls_merge(const std::vector<const std::vector<LsLaunch>*>& progs, std::vector<LsStep>& steps, std::vector<LsRec>& recs) {
@@ -2437,101 +2447,217 @@ static void ls_merge(const std::vector<const std::vector<LsLaunch>*>& progs, std
         for (size_t i = 0; i < n; ++i) { const size_t l = progs[i]->size() - pos[i]; if (l > left) { left = l; lead = i; } }
         if (lead == n) break;
         LsStep st;
-        st.type = (*progs[lead])[pos[lead]].type; st.count = 0; st.gridx = 0; st.lds = 0; st.offset = recs.size();
+        st.type = (*progs[lead])[pos[lead]].type; st.count = 0; st.blocks = 0; st.lds = 0; st.offset = recs.size();
         for (size_t i = 0; i < n; ++i) {
             if (pos[i] >= progs[i]->size()) continue;
             const LsLaunch& L = (*progs[i])[pos[i]];
             if (L.type != st.type) continue;
-            recs.push_back(L.rec);
-            st.count++; st.gridx = std::max(st.gridx, L.rec.gridx); st.lds = std::max(st.lds, L.rec.lds);
+            if (st.count == (unsigned)LS_MAX_GROUP) {          // a launch serves at most LS_MAX_GROUP LPs: the rest of the group is the next step
+                steps.push_back(st);
+                st.count = 0; st.blocks = 0; st.lds = 0; st.offset = recs.size();
+            }
+            LsRec r = L.rec;
+            r.start = st.blocks;
+            recs.push_back(r);
+            st.count++; st.blocks += L.rec.gridx; st.lds = std::max(st.lds, L.rec.lds);
             ++pos[i];
         }
         steps.push_back(st);
     }
 }
 
-extern "C" int ipm_solve_batch(ipm_handle** hs, int32_t n, double tol_p, double tol_d, double tol_gap, int32_t max_iter, ipm_stats* stats) {
-    if (!hs || n <= 0 || max_iter < 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: bad arguments");
-    for (int i = 0; i < n; ++i) {
-        if (!hs[i]) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: NULL handle");
-        if (hs[i]->device != hs[0]->device) return fail(hs[i], IPM_ERR_INVALID_ARG, "ipm_solve_batch: handles on different devices");
-        if (!ls_eligible(hs[i])) return fail(hs[i], IPM_ERR_STATE, "ipm_solve_batch: handle %d is not a lockstep handle (IPM_FLAG_LOCKSTEP, sparse A, more than 128 rows, dense-tile factor, A / b / c / state set)", i);
-    }
-    ipm_handle* h0 = hs[0];
-    HIP_TRY(h0, hipSetDevice(h0->device));
-    hipStream_t S = h0->stream;
-    static std::atomic<bool> attr_set[MAX_DEVICES];
-    if (h0->device < MAX_DEVICES && !attr_set[h0->device].load(std::memory_order_acquire)) {
-        HIP_TRY(h0, hipFuncSetAttribute((const void*)ls_adat_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8));
-        attr_set[h0->device].store(true, std::memory_order_release);
-    }
-    int chunk = 1;
-    for (int i = 0; i < n; ++i) {
-        ipm_handle* h = hs[i];
-        if (h->stream != S) HIP_TRY(h, hipStreamSynchronize(h->stream));      // everything the handle did on its own stream is complete
-        h->predictor_valid = false; h->fresh_state = false;
-        if (h->auto_reg) { h->auto_reg = 0; h->shift_rel = h->opt.regularize; }
-        hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, S, h->sc, tol_p, tol_d, tol_gap, h->opt.eta, max_iter, 0, 1);
-        int rc = enqueue_snapshot(h, 0, S);                     // roll-back point of the automatic Tikhonov shift (first chunk)
-        if (rc) return rc;
-        chunk = std::max(chunk, (int)h->opt.check_every);
-    }
-    HIP_TRY(h0, hipEventRecord(h0->ev0, S));
-    std::vector<std::vector<LsLaunch>> prog((size_t)n);
-    for (int i = 0; i < n; ++i) { int rc = ls_record_program(hs[i], prog[(size_t)i]); if (rc) return rc; }
-    std::vector<int> active((size_t)n);
-    for (int i = 0; i < n; ++i) active[(size_t)i] = i;
-    std::vector<char> first((size_t)n, 1);
+struct ipm_batch {
+    int device = 0;
+    hipStream_t S = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<ipm_handle*> hs;                       // in the order they were added
+    std::vector<std::vector<LsLaunch>> prog;
+    std::vector<char> first, finished;
+    std::vector<int> active;
     std::vector<LsStep> steps;
     std::vector<LsRec> recs;
     LsRec* d_recs = nullptr;
     size_t d_cap = 0;
-    struct Free { ipm_handle* h; LsRec** p; ~Free() { if (*p) dev_free(h->device, h->stream, *p); } } guard{h0, &d_recs};
-    bool dirty = true;
-    while (!active.empty()) {
-        if (dirty) {
-            std::vector<const std::vector<LsLaunch>*> ps;
-            for (int i : active) ps.push_back(&prog[(size_t)i]);
-            ls_merge(ps, steps, recs);
-            HIP_TRY(h0, hipStreamSynchronize(S));                   // (the table of the previous schedule may still be read)
-            if (recs.size() > d_cap) {
-                if (d_recs) dev_free(h0->device, S, d_recs);
-                d_recs = nullptr; d_cap = recs.size() + recs.size() / 4;
-                HIP_TRY(h0, dev_malloc(h0->device, S, (void**)&d_recs, sizeof(LsRec) * d_cap));
-            }
-            HIP_TRY(h0, hipMemcpyAsync(d_recs, recs.data(), sizeof(LsRec) * recs.size(), hipMemcpyHostToDevice, S));
-            HIP_TRY(h0, hipStreamSynchronize(S));                   // (`recs` is reused)
-            dirty = false;
-        }
-        for (int c = 0; c < chunk; ++c)
-            for (const LsStep& st : steps) HIP_TRY(h0, ls_launch(st.type, d_recs + st.offset, st.count, st.gridx, st.lds, S));
-        for (int i : active) HIP_TRY(hs[i], hipMemcpyAsync(hs[i]->h_sc, hs[i]->sc, sizeof(Scalars), hipMemcpyDeviceToHost, S));
-        HIP_TRY(h0, hipStreamSynchronize(S));
-        std::vector<int> keep;
-        for (int i : active) {
-            ipm_handle* h = hs[i];
-            const bool may_auto = h->opt.regularize == 0.0 && !(h->opt.flags & IPM_FLAG_NO_AUTO_REGULARIZE);
-            if (first[(size_t)i] && may_auto && h->h_sc->k > 0 && (double)h->h_sc->fixed_first > 0.05 * (double)h->m) {
-                // > 5 % dependent rows (QAP family): restart this LP from its start state with the 1e-14 Tikhonov shift (as ipm_solve does)
-                h->shift_rel = 1e-14; h->auto_reg = 1;
-                int rc = enqueue_snapshot(h, 1, S);
-                if (!rc) rc = ls_record_program(h, prog[(size_t)i]);
-                if (rc) return rc;
-                first[(size_t)i] = 0; dirty = true;
-                keep.push_back(i);
-                continue;
-            }
-            first[(size_t)i] = 0;
-            if (h->h_sc->done) { dirty = true; continue; }
-            keep.push_back(i);
-        }
-        active.swap(keep);
+    bool dirty = true, started = false;
+    int chunk = 1;
+    char err[512] = "";
+};
+static int bfail(ipm_batch* b, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof g_err, "%s", buf);
+    if (b) snprintf(b->err, sizeof b->err, "%s", buf);
+    return code;
+}
+#define B_TRY(b, call)                                                                                                        \
+    do {                                                                                                                      \
+        hipError_t e_ = (call);                                                                                               \
+        if (e_ != hipSuccess) return bfail((b), IPM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int ipm_batch_create(int device, ipm_batch** out) {
+    if (!out) return bfail(nullptr, IPM_ERR_INVALID_ARG, "ipm_batch_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return bfail(nullptr, IPM_ERR_NO_DEVICE, "ipm_batch_create: device %d not visible", device);
+    ipm_batch* b = new ipm_batch();
+    b->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->S, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+    static std::atomic<bool> attr_set[MAX_DEVICES];
+    if (e == hipSuccess && device < MAX_DEVICES && !attr_set[device].load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute((const void*)ls_adat_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8);
+        attr_set[device].store(true, std::memory_order_release);
     }
-    HIP_TRY(h0, hipEventRecord(h0->ev1, S));
-    HIP_TRY(h0, hipEventSynchronize(h0->ev1));
+    if (e != hipSuccess) { const int rc = bfail(nullptr, IPM_ERR_HIP, "ipm_batch_create: %s", hipGetErrorString(e)); if (b->S) (void)hipStreamDestroy(b->S); delete b; return rc; }
+    *out = b;
+    return IPM_OK;
+}
+extern "C" int ipm_batch_destroy(ipm_batch* b) {
+    if (!b) return IPM_OK;
+    (void)hipSetDevice(b->device);
+    if (b->S) (void)hipStreamSynchronize(b->S);
+    if (b->d_recs) dev_free(b->device, b->S, b->d_recs);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->S) { (void)hipStreamSynchronize(b->S); (void)hipStreamDestroy(b->S); }
+    delete b;
+    return IPM_OK;
+}
+extern "C" const char* ipm_batch_last_error(const ipm_batch* b) { return b ? b->err : g_err; }
+
+// A handle joins the batch (at any time between two ipm_batch_step calls): its solve starts from its current state with these
+// tolerances, exactly as ipm_solve would start it.  *index = its position in the batch (what ipm_batch_step reports).
+extern "C" int ipm_batch_add(ipm_batch* b, ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t max_iter, int32_t* index) {
+    if (!b || !h || max_iter < 0) return bfail(b, IPM_ERR_INVALID_ARG, "ipm_batch_add: bad arguments");
+    if (h->device != b->device) return bfail(b, IPM_ERR_INVALID_ARG, "ipm_batch_add: the handle lives on device %d, the batch on %d", h->device, b->device);
+    if (!ls_eligible(h)) return bfail(b, IPM_ERR_STATE, "ipm_batch_add: not a lockstep handle (IPM_FLAG_LOCKSTEP, sparse A, more than 128 rows, dense-tile factor, A / b / c / state set)");
+    B_TRY(b, hipSetDevice(b->device));
+    if (h->stream != b->S) B_TRY(b, hipStreamSynchronize(h->stream));      // everything the handle did on its own stream is complete
+    h->predictor_valid = false; h->fresh_state = false;
+    if (h->auto_reg) { h->auto_reg = 0; h->shift_rel = h->opt.regularize; }
+    if (!b->started) { B_TRY(b, hipEventRecord(b->ev0, b->S)); b->started = true; }
+    hipLaunchKernelGGL(set_params_kernel, dim3(1), dim3(1), 0, b->S, h->sc, tol_p, tol_d, tol_gap, h->opt.eta, max_iter, 0, 1);
+    int rc = enqueue_snapshot(h, 0, b->S);                     // roll-back point of the automatic Tikhonov shift (first chunk)
+    if (rc) return bfail(b, rc, "%s", h->err);
+    std::vector<LsLaunch> pr;
+    if ((rc = ls_record_program(h, pr))) return bfail(b, rc, "%s", h->err);
+    const int idx = (int)b->hs.size();
+    b->hs.push_back(h); b->prog.push_back(std::move(pr)); b->first.push_back(1); b->finished.push_back(0);
+    b->active.push_back(idx);
+    b->chunk = std::max(b->chunk, (int)h->opt.check_every);
+    b->dirty = true;
+    if (index) *index = idx;
+    return IPM_OK;
+}
+
+// One chunk (check_every iterations) of every active handle in lockstep, then the stop flags are read: the indices of the
+// handles that finished in this chunk go to finished[0 .. *n_finished) (capacity cap), *n_active = handles still running.
+extern "C" int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int32_t* n_finished, int32_t* n_active) {
+    if (!b || !n_finished || (cap > 0 && !finished)) return bfail(b, IPM_ERR_INVALID_ARG, "ipm_batch_step: bad arguments");
+    *n_finished = 0;
+    if (n_active) *n_active = (int32_t)b->active.size();
+    if (b->active.empty()) return IPM_OK;
+    B_TRY(b, hipSetDevice(b->device));
+    hipStream_t S = b->S;
+    if (b->dirty) {
+        std::vector<const std::vector<LsLaunch>*> ps;
+        for (int i : b->active) ps.push_back(&b->prog[(size_t)i]);
+        ls_merge(ps, b->steps, b->recs);
+        B_TRY(b, hipStreamSynchronize(S));                   // (the table of the previous schedule may still be read)
+        if (b->recs.size() > b->d_cap) {
+            if (b->d_recs) dev_free(b->device, S, b->d_recs);
+            b->d_recs = nullptr; b->d_cap = b->recs.size() + b->recs.size() / 2;
+            B_TRY(b, dev_malloc(b->device, S, (void**)&b->d_recs, sizeof(LsRec) * b->d_cap));
+        }
+        B_TRY(b, hipMemcpyAsync(b->d_recs, b->recs.data(), sizeof(LsRec) * b->recs.size(), hipMemcpyHostToDevice, S));
+        B_TRY(b, hipStreamSynchronize(S));                   // (`recs` is reused)
+        b->dirty = false;
+        if (getenv("IPM_LS_DEBUG")) {
+            size_t longest = 0; int cnt[LS_NTYPES] = {0};
+            for (int i : b->active) longest = std::max(longest, b->prog[(size_t)i].size());
+            for (const LsStep& st : b->steps) cnt[st.type]++;
+            fprintf(stderr, "[lockstep] %zu LPs active, longest program %zu launches, merged schedule %zu steps (%zu records); steps by type:", b->active.size(), longest, b->steps.size(), b->recs.size());
+            for (int t = 0; t < LS_NTYPES; ++t) if (cnt[t]) fprintf(stderr, " %d:%d", t, cnt[t]);
+            fprintf(stderr, "\n");
+        }
+    }
+    static const bool ls_prof = getenv("IPM_LS_PROF") != nullptr;      // diagnostic: a synchronisation after every launch, wall time per kernel type
+    if (ls_prof) {
+        static double tot[LS_NTYPES]; static long cnt[LS_NTYPES]; static long calls = 0;
+        for (int c = 0; c < b->chunk; ++c)
+            for (const LsStep& st : b->steps) {
+                const auto t0 = std::chrono::steady_clock::now();
+                B_TRY(b, ls_launch(st.type, b->d_recs + st.offset, st.count, st.blocks, st.lds, S));
+                B_TRY(b, hipStreamSynchronize(S));
+                tot[st.type] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); cnt[st.type]++;
+            }
+        if (++calls % 25 == 0) {
+            fprintf(stderr, "[lockstep prof] %zu active, %zu steps; us per launch (launches) by type:", b->active.size(), b->steps.size());
+            for (int t = 0; t < LS_NTYPES; ++t) if (cnt[t]) fprintf(stderr, " %d:%.1f(%ld)", t, 1e6 * tot[t] / cnt[t], cnt[t]);
+            fprintf(stderr, "\n");
+            for (int t = 0; t < LS_NTYPES; ++t) { tot[t] = 0; cnt[t] = 0; }
+        }
+    } else
+    for (int c = 0; c < b->chunk; ++c)
+        for (const LsStep& st : b->steps) B_TRY(b, ls_launch(st.type, b->d_recs + st.offset, st.count, st.blocks, st.lds, S));
+    for (int i : b->active) B_TRY(b, hipMemcpyAsync(b->hs[(size_t)i]->h_sc, b->hs[(size_t)i]->sc, sizeof(Scalars), hipMemcpyDeviceToHost, S));
+    B_TRY(b, hipStreamSynchronize(S));
+    std::vector<int> keep;
+    for (int i : b->active) {
+        ipm_handle* h = b->hs[(size_t)i];
+        const bool may_auto = h->opt.regularize == 0.0 && !(h->opt.flags & IPM_FLAG_NO_AUTO_REGULARIZE);
+        if (b->first[(size_t)i] && may_auto && h->h_sc->k > 0 && (double)h->h_sc->fixed_first > 0.05 * (double)h->m) {
+            // > 5 % dependent rows (QAP family): restart this LP from its start state with the 1e-14 Tikhonov shift (as ipm_solve does)
+            h->shift_rel = 1e-14; h->auto_reg = 1;
+            int rc = enqueue_snapshot(h, 1, S);
+            if (!rc) rc = ls_record_program(h, b->prog[(size_t)i]);
+            if (rc) return bfail(b, rc, "%s", h->err);
+            b->first[(size_t)i] = 0; b->dirty = true;
+            keep.push_back(i);
+            continue;
+        }
+        b->first[(size_t)i] = 0;
+        if (h->h_sc->done) {
+            b->dirty = true; b->finished[(size_t)i] = 1;
+            if (*n_finished < cap) finished[(*n_finished)++] = i;
+            continue;
+        }
+        keep.push_back(i);
+    }
+    b->active.swap(keep);
+    if (n_active) *n_active = (int32_t)b->active.size();
+    return IPM_OK;
+}
+extern "C" int ipm_batch_stats(ipm_batch* b, int32_t index, ipm_stats* stats) {
+    if (!b || index < 0 || index >= (int32_t)b->hs.size() || !stats) return bfail(b, IPM_ERR_INVALID_ARG, "ipm_batch_stats: bad arguments");
     float ms = 0.f;
-    HIP_TRY(h0, hipEventElapsedTime(&ms, h0->ev0, h0->ev1));
-    if (stats) for (int i = 0; i < n; ++i) fill_stats(hs[i], &stats[i], ms);
+    if (b->started) {
+        (void)hipSetDevice(b->device);
+        if (hipEventRecord(b->ev1, b->S) == hipSuccess && hipEventSynchronize(b->ev1) == hipSuccess) (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
+    }
+    fill_stats(b->hs[(size_t)index], stats, ms);             // (the handle's host mirror of the scalars was read by the step that saw it finish)
+    return IPM_OK;
+}
+
+extern "C" int ipm_solve_batch(ipm_handle** hs, int32_t n, double tol_p, double tol_d, double tol_gap, int32_t max_iter, ipm_stats* stats) {
+    if (!hs || n <= 0 || max_iter < 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: bad arguments");
+    for (int i = 0; i < n; ++i) if (!hs[i]) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: NULL handle");
+    ipm_batch* b = nullptr;
+    int rc = ipm_batch_create(hs[0]->device, &b);
+    if (rc) return rc;
+    struct Guard { ipm_batch* b; ~Guard() { ipm_batch_destroy(b); } } guard{b};
+    for (int i = 0; i < n && !rc; ++i) { rc = ipm_batch_add(b, hs[i], tol_p, tol_d, tol_gap, max_iter, nullptr); if (rc) snprintf(hs[i]->err, sizeof hs[i]->err, "%s", b->err); }
+    int32_t nfin = 0, nact = n;
+    std::vector<int32_t> fin((size_t)n);
+    while (!rc && nact > 0) rc = ipm_batch_step(b, fin.data(), n, &nfin, &nact);
+    if (rc) { snprintf(hs[0]->err, sizeof hs[0]->err, "%s", b->err); return rc; }
+    if (stats) for (int i = 0; i < n; ++i) ipm_batch_stats(b, i, &stats[i]);
     return IPM_OK;
 }
 

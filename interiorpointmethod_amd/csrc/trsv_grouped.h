@@ -27,15 +27,16 @@ constexpr int GS_MAX = 8;             // 128-blocks per group: 8 from 16 blocks 
 
 // X_g[a*128 + r][a*128 + c] = inv(L_bb)[r][c] and XT_g = its transpose, for every 128-block b = GS g + a.
 // grid (4, 4, nblocks), block (32, 8).
-__global__ void group_diag_transpose_kernel(const double* __restrict__ invD, double* XT, double* X, int b0, int GS, const int* done) {
+__device__ __forceinline__ void group_diag_transpose_kernel_body(const double* __restrict__ invD, double* XT, double* X, int b0, int GS, const int* done,
+                                                                  const unsigned bx_, const unsigned by_, const unsigned bz_) {
     if (done && *done) return;
     __shared__ double tile[32][33];
     const int64_t GR = (int64_t)GS * 128;
-    const int b = b0 + blockIdx.z, g = b / GS, a = b % GS;
+    const int b = b0 + bz_, g = b / GS, a = b % GS;
     const double* src = invD + (int64_t)b * 128 * 128;
     double* dst = XT + (int64_t)g * GR * GR + (int64_t)(a * 128) * GR + a * 128;
     double* dsx = X + (int64_t)g * GR * GR + (int64_t)(a * 128) * GR + a * 128;
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int bx = bx_ * 32, by = by_ * 32;
     for (int j = threadIdx.y; j < 32; j += 8) {
         double v = src[(int64_t)(by + j) * 128 + bx + threadIdx.x];
         tile[j][threadIdx.x] = v;
@@ -44,12 +45,15 @@ __global__ void group_diag_transpose_kernel(const double* __restrict__ invD, dou
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += 8) dst[(int64_t)(bx + j) * GR + by + threadIdx.x] = tile[threadIdx.x][j];
 }
+__global__ void group_diag_transpose_kernel(const double* __restrict__ invD, double* XT, double* X, int b0, int GS, const int* done) {
+    group_diag_transpose_kernel_body(invD, XT, X, b0, GS, done, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // z[c] -= sum_rc part[rc*np + c], c < np  (fixed order)
-__global__ __launch_bounds__(256) void sub_partials_kernel(double* z, const double* __restrict__ part, int np, int rc,
-                                                           const int* done) {
+__device__ __forceinline__ void sub_partials_kernel_body(double* z, const double* __restrict__ part, int np, int rc,
+                                                           const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = bx_ * 256 + threadIdx.x;
     if (c >= np) return;
     double s = 0.0;
     int r = 0;
@@ -63,5 +67,7 @@ __global__ __launch_bounds__(256) void sub_partials_kernel(double* z, const doub
     for (; r < rc; ++r) s += part[(int64_t)r * np + c];
     z[c] -= s;
 }
+__global__ __launch_bounds__(256) void sub_partials_kernel(double* z, const double* __restrict__ part, int np, int rc,
+                                                           const int* done) { sub_partials_kernel_body(z, part, np, rc, done, blockIdx.x, gridDim.x); }
 
 }  // namespace ipm

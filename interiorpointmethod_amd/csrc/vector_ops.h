@@ -88,13 +88,13 @@ __device__ __forceinline__ double min_partials(const double* part, int slot, int
 // GEMV, A row-major [mp][np] (zero padded).
 // ---------------------------------------------------------------------------------------
 // out[i] = sa * (A[i,:] . v) + sb * add[i]   -- one wave per row, 16 B per lane per step.
-__global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, int64_t lda, int mp,
+__device__ __forceinline__ void gemv_n_kernel_body(const double* __restrict__ A, int64_t lda, int mp,
                                                      int np, const double* __restrict__ v, double sa,
                                                      double sb, const double* __restrict__ add,
-                                                     double* out, const int* done) {
+                                                     double* out, const int* done, const unsigned bx_, const unsigned gx_) {
     if (done && *done) return;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = bx_ * 4 + (threadIdx.x >> 6);
     if (row >= mp) return;
     const double* ar = A + (int64_t)row * lda;
     double acc0 = 0.0, acc1 = 0.0;
@@ -108,15 +108,19 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) out[row] = sa * s + (add ? sb * add[row] : 0.0);
 }
+__global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, int64_t lda, int mp,
+                                                     int np, const double* __restrict__ v, double sa,
+                                                     double sb, const double* __restrict__ add,
+                                                     double* out, const int* done) { gemv_n_kernel_body(A, lda, mp, np, v, sa, sb, add, out, done, blockIdx.x, gridDim.x); }
 
 // part[rc][c] = sum_{r in chunk rc} A[r][c] * u[r]  -- grid (ceil(np/512), RC); 2 columns/thread.
-__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int64_t lda, int rows_per_chunk,
+__device__ __forceinline__ void gemv_t_kernel_body(const double* __restrict__ A, int64_t lda, int rows_per_chunk,
                                                      int np, const double* __restrict__ u, double* part,
-                                                     const int* done) {
+                                                     const int* done, const unsigned bx_, const unsigned by_) {
     if (done && *done) return;
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int c = (bx_ * 256 + threadIdx.x) * 2;
     if (c >= np) return;
-    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r0 = by_ * rows_per_chunk;
     double a0 = 0.0, a1 = 0.0;
     const double* ap = A + (int64_t)r0 * lda + c;
 #pragma unroll 8
@@ -126,8 +130,11 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ 
         a0 += a2.x * ur;
         a1 += a2.y * ur;
     }
-    *reinterpret_cast<f64x2*>(part + (int64_t)blockIdx.y * np + c) = (f64x2){a0, a1};
+    *reinterpret_cast<f64x2*>(part + (int64_t)by_ * np + c) = (f64x2){a0, a1};
 }
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int64_t lda, int rows_per_chunk,
+                                                     int np, const double* __restrict__ u, double* part,
+                                                     const int* done) { gemv_t_kernel_body(A, lda, rows_per_chunk, np, u, part, done, blockIdx.x, blockIdx.y); }
 
 struct VecArgs {
     int m, n, np, rc_chunks;       // true sizes, padded n, number of gemv_t row chunks

@@ -484,6 +484,58 @@ def solve_lockstep(solvers, tol=1e-8, max_iter=5000, tol_gap=None):
     return out
 
 
+class LockstepBatch:
+    """ipm_batch_*: the lockstep batch, incrementally.  add(solver) lets an IpmSolver (lockstep=True, a state set) JOIN between two
+    steps; step() runs opt.check_every iterations of every active LP in the same launches and returns the solvers that finished,
+    each with its statistics in solver.stats.  The solvers stay owned by the caller (close them after they are reported finished)."""
+
+    def __init__(self, device=0, tol=1e-8, max_iter=5000, tol_gap=None):
+        self._lib = _lib.load()
+        self._b = C.c_void_p()
+        _lib.check(None, self._lib.ipm_batch_create(int(device), C.byref(self._b)))
+        self.tol, self.max_iter, self.tol_gap = float(tol), int(max_iter), float(tol if tol_gap is None else tol_gap)
+        self.solvers = []
+        self.active = 0
+
+    def _check(self, code):
+        if code != _lib.IPM_OK:
+            raise _lib.IpmError(code, (self._lib.ipm_batch_last_error(self._b) or b"").decode("utf-8", "replace"))
+
+    def add(self, solver):
+        idx = C.c_int32(-1)
+        self._check(self._lib.ipm_batch_add(self._b, solver._h, self.tol, self.tol, self.tol_gap, self.max_iter, C.byref(idx)))
+        assert idx.value == len(self.solvers)
+        self.solvers.append(solver)
+        self.active += 1
+        return idx.value
+
+    def step(self):
+        cap = max(1, len(self.solvers))
+        fin = (C.c_int32 * cap)()
+        nf, na = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.ipm_batch_step(self._b, fin, cap, C.byref(nf), C.byref(na)))
+        self.active = na.value
+        out = []
+        for k in range(nf.value):
+            sv = self.solvers[fin[k]]
+            st = _lib.Stats()
+            self._check(self._lib.ipm_batch_stats(self._b, fin[k], C.byref(st)))
+            sv.stats = st.as_dict()
+            out.append(sv)
+        return out
+
+    def close(self):
+        if self._b:
+            self._lib.ipm_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def lockstep_eligible(solver):
     """Can this IpmSolver join solve_lockstep?  Sparse A on the dense-tile factor, more than 128 rows (the small LPs have their fused
     single-workgroup kernel, the sparse-factor LPs their tree sweeps)."""

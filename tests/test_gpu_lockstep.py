@@ -87,3 +87,58 @@ def test_lockstep_rejects_handles_it_cannot_serve():
         sv.init_state(1.0)
         with pytest.raises(ipm.IpmError):
             ipm.solve_lockstep([sv])
+
+
+def test_lockstep_batch_lets_an_lp_join_between_two_steps():
+    """ipm_batch_add between two ipm_batch_step calls: the late LP starts at ITS iteration 0 next to neighbours that are several
+    iterations in, and still ends bit-identical to the handle solved alone (batch.solve_shard_lockstep feeds its batches this way
+    while the set-up threads are still preparing the next LPs)."""
+    names = ["SCFXM1", "BANDM", "DEGEN3", "E226"]
+    probs = [_load(nm) for nm in names]
+    ref = [_alone(*p, 300) for p in probs]
+    svs = [ipm.IpmSolver(*p, lockstep=True, factor="dense") for p in probs]
+    try:
+        for sv in svs:
+            sv.init_state(1.0)
+        done = []
+        with ipm.LockstepBatch(tol=1e-8, max_iter=300) as bt:
+            bt.add(svs[0]); bt.add(svs[1])
+            done += bt.step(); done += bt.step()
+            bt.add(svs[2])
+            done += bt.step()
+            bt.add(svs[3])
+            for _ in range(400):
+                if not bt.active:
+                    break
+                done += bt.step()
+            assert bt.active == 0
+        assert sorted(id(s) for s in done) == sorted(id(s) for s in svs)
+        for nm, sv, (st0, (x0, y0, s0)) in zip(names, svs, ref):
+            x, y, s = sv.get_state()
+            st = sv.stats
+            assert (st["status"], st["iterations"]) == (st0["status"], st0["iterations"]), (nm, st, st0)
+            assert st["objective"] == st0["objective"] or (np.isnan(st["objective"]) and np.isnan(st0["objective"])), nm
+            assert np.array_equal(x, x0, equal_nan=True) and np.array_equal(y, y0, equal_nan=True) and np.array_equal(s, s0, equal_nan=True), nm
+    finally:
+        for sv in svs:
+            sv.close()
+
+
+def test_run_batch_lockstep_equals_the_one_at_a_time_table():
+    """batch.run_batch(lockstep=True) -- what bench.py's Netlib legs run: size-class batches, the small and sparse-factor LPs on
+    their own kernels beside them -- must print the table of the one-at-a-time driver loop (script.py:147-173): same status and
+    iteration count per LP, objectives equal to 1e-9 relative (a lockstep handle forms and factors with the single-stream tile
+    shapes, which associate the sums exactly like the wide-tile kernels; the bound leaves room for a shape rule that does not)."""
+    from interiorpointmethod_amd import batch
+    names = ["AFIRO", "ADLITTLE", "BANDM", "SCFXM1", "E226", "DEGEN3", "BNL1", "WOODW", "25FV47", "SEBA", "SC205", "GFRD-PNC",
+             "SCTAP3", "SHELL", "QAP8", "TRUSS", "SCSD8", "STOCFOR2"]
+    probs = [_load(nm) for nm in names]
+    ls, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=8, lockstep=True)
+    seq, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=1)
+    F = batch.RECORD_FIELDS
+    assert np.array_equal(ls[:, 0], np.arange(len(names))) and set(ls[:, 1].tolist()) <= {1.0, 2.0, 3.0}
+    assert not ls[:, F.index("timeouts_recovered")].any() and not ls[:, F.index("serial_launches")].any()
+    assert np.array_equal(seq[:, 1:3], ls[:, 1:3]), [(n, a[1:3], b[1:3]) for n, a, b in zip(names, seq, ls) if not np.array_equal(a[1:3], b[1:3])]
+    for nm, a, b in zip(names, seq, ls):
+        assert (np.isnan(a[3]) and np.isnan(b[3])) or abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(a[3])), (nm, a[3], b[3])
+    assert np.all(ls[:, F.index("solve_seconds")] > 0)

@@ -95,7 +95,7 @@ def solve_one(problem, device=0, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0
     return info
 
 
-def _in_own_stream(solve_fn, problem, device, kw):
+def _in_own_stream(solve_fn, problem, device, kw, stream=None):
     """Run solve_fn with a torch stream of its own as the thread's current stream (a handle binds to the current
     stream), so solves issued from different host threads overlap on the GPU.  (High-priority streams for the largest LPs
     were measured in round 4 and make the suite SLOWER: 14.5 LPs/s without, 13.0 / 13.3 / 11.2 with the LPs of >= 1000 /
@@ -103,7 +103,7 @@ def _in_own_stream(solve_fn, problem, device, kw):
     try:
         import torch
         if torch.cuda.is_available():
-            with torch.cuda.device(device), torch.cuda.stream(torch.cuda.Stream(device=device)):
+            with torch.cuda.device(device), torch.cuda.stream(stream if stream is not None else torch.cuda.Stream(device=device)):
                 return solve_fn(problem, device=device, **kw)
     except ImportError:
         pass
@@ -152,24 +152,29 @@ def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
     return rec
 
 
+# Tuning of solve_shard_lockstep (one MI355X, the 73 Netlib LPs; DESIGN.md 6 has the sweeps):
 LOCKSTEP_MAX_ROWS = int(__import__("os").environ.get("IPM_LOCKSTEP_MAX_ROWS", 1 << 30))
-# host threads (= streams) that solve the LPs outside the batches (up to 128 rows, sparse factor) one after the other: with one
-# stream per batch and these, the rank uses about as many streams as the GPU has hardware queues
-LOCKSTEP_CLASSIC_THREADS = int(__import__("os").environ.get("IPM_LOCKSTEP_CLASSIC_THREADS", 2))
-# row limits of the size classes of the lockstep batches (one batch per class; the last class is open ended)
-LOCKSTEP_CLASSES = [int(v) for v in __import__("os").environ.get("IPM_LOCKSTEP_CLASSES", "1100,2200").split(",") if v]
+# row limits of the size classes (one batch, one stream, one host thread per class; the last class is open ended).  Every step of a
+# batch lasts as long as its slowest LP's kernel, so very different sizes in one batch inflate each other's chain
+LOCKSTEP_CLASSES = [int(v) for v in __import__("os").environ.get("IPM_LOCKSTEP_CLASSES", "2200,3500").split(",") if v]
+# host threads (= streams) for the LPs outside the batches (up to 128 rows, sparse factor), solved one after the other.  Batches +
+# these should not be more than the four hardware queues HIP multiplexes its streams onto: a fifth stream costs 25 % of the suite
+LOCKSTEP_CLASSIC_THREADS = int(__import__("os").environ.get("IPM_LOCKSTEP_CLASSIC_THREADS", 1))
+# up to this many rows an LP takes the dense-tile factor (and joins a batch) even where a lone solve would take the sparse one
+LOCKSTEP_DENSE_ROWS = int(__import__("os").environ.get("IPM_LOCKSTEP_DENSE_ROWS", 3500))
 
 
 def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, tol_gap=None, **_):
     """Solve problems[i] for i in ids on this rank's GPU with the LOCKSTEP BATCH -> (len(ids), NF) records.
 
-    `workers` host threads prepare the LPs (host analysis, handle, upload), largest first.  LPs the batch cannot serve -- up to 128
-    rows (fused single-workgroup kernel) and the ones `factor="auto"` puts on the sparse multifrontal factor -- are solved by their
-    thread right away, each on a stream of its own, as in solve_shard.  Every other LP JOINS the one running batch as soon as its
-    handle is ready (ipm_batch_add between two steps): iteration k of all of them in the same launches (csrc/lockstep.h), so that
-    the rank's chain of launches is that of its longest LP instead of eight chains that share four hardware queues.  Finished LPs
-    are read back and destroyed by the pool while the batch runs on.  Per-LP results are those of a one-at-a-time solve of the
-    same handle, bit for bit (tests/test_gpu_lockstep.py)."""
+    `workers` host threads prepare the LPs (host analysis, handle, upload), largest first.  An LP of more than 128 rows on the
+    dense-tile factor JOINS the running batch of its size class as soon as its handle is ready (ipm_batch_add between two steps):
+    iteration k of all LPs of a class in the same launches (csrc/lockstep.h), so that the rank's chains of launches are those of
+    the longest LP of each class instead of eight chains that share four hardware queues.  The LPs a batch cannot serve -- up to
+    128 rows (fused single-workgroup kernel), the sparse multifrontal factor above LOCKSTEP_DENSE_ROWS rows -- are solved one after
+    the other on LOCKSTEP_CLASSIC_THREADS streams, and by the class threads once their batch has finished.  Finished LPs are read
+    back and destroyed by the pool while the batches run on.  Per-LP results are those of a one-at-a-time solve of the same
+    handle, bit for bit (tests/test_gpu_lockstep.py)."""
     import queue
     from concurrent.futures import ThreadPoolExecutor
     from . import _lib
@@ -194,7 +199,9 @@ def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=
         t0 = time.perf_counter()
         sv, handed = None, False
         try:
-            prepared = prepare(A, b, c)                     # host analysis ONCE: row order, factor path
+            # host analysis ONCE: row order, factor path.  Up to LOCKSTEP_DENSE_ROWS rows the dense-tile factor even where a lone solve
+            # would take the sparse one: inside a batch an LP whose program is shorter than the class leader's adds no launches
+            prepared = prepare(A, b, c, factor=("dense" if wants_lockstep(i) and A.shape[0] <= LOCKSTEP_DENSE_ROWS else None))
             if wants_lockstep(i) and prepared.factor != "sparse":
                 sv = IpmSolver(A, b, c, device=device, regularize=regularize, lockstep=True, concurrent=True, prepared=prepared)
                 if lockstep_eligible(sv):
@@ -219,13 +226,21 @@ def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=
         rec[row] = _row(i, info)
 
     def classic_runner():
+        own = None                      # ONE stream per runner for all its LPs: a new stream per LP walks through the hardware queues
+        if __import__("os").environ.get("IPM_LOCKSTEP_FIXED_STREAMS", "1") != "0":
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    own = torch.cuda.Stream(device=device)
+            except ImportError:
+                pass
         while True:
             item = classic_q.get()
             if item is None:
                 return
             row, i, prepared, t0 = item
             try:
-                info = _in_own_stream(classic, problems[i], device, dict(prepared=prepared))
+                info = _in_own_stream(classic, problems[i], device, dict(prepared=prepared), stream=own)
             except Exception as e:
                 import sys
                 A = problems[i][0]
@@ -309,13 +324,18 @@ def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=
                 except Exception:
                     pass
 
-    runners = [threading.Thread(target=run_class, args=(k,)) for k in range(ncls)]
+    def run_class_then_classic(k):
+        run_class(k)
+        if expected[k] and __import__("os").environ.get("IPM_LOCKSTEP_STEAL", "1") != "0":
+            classic_runner()            # its batch is finished, its stream idle: help with the LPs outside the batches
+
+    runners = [threading.Thread(target=run_class_then_classic, args=(k,)) for k in range(ncls)]
     crunners = [threading.Thread(target=classic_runner) for _ in range(max(1, LOCKSTEP_CLASSIC_THREADS))]
     for t in runners + crunners:
         t.start()
     for f in futs:
         f.result()                       # every LP is set up: the classic queue is complete
-    for _ in crunners:
+    for _ in crunners + runners:
         classic_q.put(None)
     for t in runners + crunners:
         t.join()

@@ -2480,6 +2480,8 @@ struct ipm_batch {
     size_t d_cap = 0;
     bool dirty = true, started = false;
     int chunk = 1;
+    double t_merge = 0, t_enqueue = 0, t_wait = 0;     // IPM_LS_DEBUG: host seconds merging schedules, enqueueing launches, waiting for the chunk
+    long n_launch = 0, n_merge = 0;
     char err[512] = "";
 };
 static int bfail(ipm_batch* b, int code, const char* fmt, ...) {
@@ -2522,6 +2524,9 @@ extern "C" int ipm_batch_destroy(ipm_batch* b) {
     if (!b) return IPM_OK;
     (void)hipSetDevice(b->device);
     if (b->S) (void)hipStreamSynchronize(b->S);
+    if (getenv("IPM_LS_DEBUG"))
+        fprintf(stderr, "[lockstep] batch of %zu LPs: %ld launches, host %.3f s enqueueing (%.1f us per launch) + %.3f s waiting for the chunks + %.3f s in %ld schedule merges\n",
+                b->hs.size(), b->n_launch, b->t_enqueue, b->n_launch ? 1e6 * b->t_enqueue / (double)b->n_launch : 0.0, b->t_wait, b->t_merge, b->n_merge);
     if (b->d_recs) dev_free(b->device, b->S, b->d_recs);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -2565,6 +2570,8 @@ extern "C" int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int3
     if (b->active.empty()) return IPM_OK;
     B_TRY(b, hipSetDevice(b->device));
     hipStream_t S = b->S;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     if (b->dirty) {
         std::vector<const std::vector<LsLaunch>*> ps;
         for (int i : b->active) ps.push_back(&b->prog[(size_t)i]);
@@ -2578,6 +2585,7 @@ extern "C" int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int3
         B_TRY(b, hipMemcpyAsync(b->d_recs, b->recs.data(), sizeof(LsRec) * b->recs.size(), hipMemcpyHostToDevice, S));
         B_TRY(b, hipStreamSynchronize(S));                   // (`recs` is reused)
         b->dirty = false;
+        b->t_merge += secs(t_in); b->n_merge++;
         if (getenv("IPM_LS_DEBUG")) {
             size_t longest = 0; int cnt[LS_NTYPES] = {0};
             for (int i : b->active) longest = std::max(longest, b->prog[(size_t)i].size());
@@ -2587,6 +2595,7 @@ extern "C" int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int3
             fprintf(stderr, "\n");
         }
     }
+    const auto t_mid = std::chrono::steady_clock::now();
     static const bool ls_prof = getenv("IPM_LS_PROF") != nullptr;      // diagnostic: a synchronisation after every launch, wall time per kernel type
     if (ls_prof) {
         static double tot[LS_NTYPES]; static long cnt[LS_NTYPES]; static long calls = 0;
@@ -2607,7 +2616,16 @@ extern "C" int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int3
     for (int c = 0; c < b->chunk; ++c)
         for (const LsStep& st : b->steps) B_TRY(b, ls_launch(st.type, b->d_recs + st.offset, st.count, st.blocks, st.lds, S));
     for (int i : b->active) B_TRY(b, hipMemcpyAsync(b->hs[(size_t)i]->h_sc, b->hs[(size_t)i]->sc, sizeof(Scalars), hipMemcpyDeviceToHost, S));
+    b->t_enqueue += secs(t_mid); b->n_launch += (long)b->chunk * (long)b->steps.size();
+    const auto t_w = std::chrono::steady_clock::now();
     B_TRY(b, hipStreamSynchronize(S));
+    b->t_wait += secs(t_w);
+    if (getenv("IPM_LS_DEBUG") && atoi(getenv("IPM_LS_DEBUG")) >= 2) {
+        size_t longest = 0, lead = 0;
+        for (int i : b->active) if (b->prog[(size_t)i].size() > longest) { longest = b->prog[(size_t)i].size(); lead = (size_t)i; }
+        fprintf(stderr, "[lockstep chunk] batch %p: %zu active, %zu steps (longest program %zu: %d rows), %.3f ms per iteration\n", (void*)b, b->active.size(),
+                b->steps.size(), longest, (int)b->hs[lead]->m, 1e3 * secs(t_mid) / b->chunk);
+    }
     std::vector<int> keep;
     for (int i : b->active) {
         ipm_handle* h = b->hs[(size_t)i];

@@ -303,18 +303,27 @@ constexpr int PD_THREADS = 512;      // 8 waves: wave 0 runs the serial pivot ch
 // have passed a barrier after the last write to W.  Returns the number of guarded pivots (meaningful on wave 0).
 // nt = 8 is the 128 x 128 diagonal block of the blocked factorization (potrf_diag_kernel); the fused small-LP kernel
 // (small_lp.h) calls it with nt = ceil(m / 16).
-struct NoEarlyWork { __device__ __forceinline__ void operator()() const {} };
+// Hooks of potrf_lds for work that only READS what is already final (the write-back of potrf_diag_body): panel(jb, part, nparts) is
+// called in P3(jb) by every wave except the one on the pivot chain, behind its share of the panel's items (L rows of the tiles up
+// to jb and the inverse rows of the tiles up to jb-2 are final there); last() by every wave behind its tile of the last inverse row.
+struct NoEarlyWork {
+    __device__ __forceinline__ void panel(int, int, int) const {}
+    __device__ __forceinline__ void last() const {}
+};
 
+// tile0_done: the caller has factored tile (0,0) itself (factor_tile with `pre`) and every wave has passed a barrier since.
 template <bool STAMP, typename Early = NoEarlyWork>
 __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, double thresh, double big, long long* stamps,
-                                         Early early = Early()) {
+                                         Early early = Early(), bool tile0_done = false) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     int nfix = 0;
-    if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, big, dinv_s);
-    IPM_STAMP(2);
-    __syncthreads();
+    if (!tile0_done) {
+        if (wave == 0) nfix += factor_tile(W, 0, lane, thresh, big, dinv_s);
+        IPM_STAMP(2);
+        __syncthreads();
+    }
     IPM_STAMP(3);
 
     // Phase schedule per 16-wide panel jb (two barriers per panel):
@@ -364,17 +373,18 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
                     inverse_tile(W, jb - 1, it - nupd, fr, fk);
                 }
             }
+            early.panel(jb, (nrt > 0) ? wave - 1 : wave, (nrt > 0) ? 7 : 8);
         }
         IPM_STAMP(6 + jb * 4);
         __syncthreads();
         IPM_STAMP(7 + jb * 4);
     }
     // last block row of inv(L): needs the tile inverse of the last panel (made in its P3) and the row above it.
-    // `early` (optional): work that only READS what is already final -- L and the inverse rows above the last one -- runs
-    // here, per wave, right behind that wave's tile of the last row: the tiles are uneven (nt-1 ... 1 products), so the
-    // write-back of the blocked factorization hides under the longest of them instead of following it.
+    // early.last() (optional): work that only READS what is already final -- L and the inverse rows above the last one -- runs
+    // here, per wave, right behind that wave's tile of the last row: the tiles are uneven (nt-1 ... 1 products), so what is left
+    // of the write-back of the blocked factorization hides under the longest of them instead of following it.
     for (int jt = wave; jt < nt - 1; jt += 8) inverse_tile(W, nt - 1, jt, fr, fk);
-    early();
+    early.last();
     IPM_STAMP(38);
     __syncthreads();
     IPM_STAMP(39);
@@ -414,24 +424,40 @@ __device__ __forceinline__ void potrf_diag_body(const PotrfDiag& a, double* W, d
     if (a.trace && tid == 0) a.trace[1] = (long long)wall_clock64();
 
     IPM_STAMP(0);
-    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a
-    //      thread are issued before the first LDS write (one memory latency)
+    // ---- load the block (rows complete up to the end of their 16-wide diagonal tile): all loads of a thread are issued before the
+    //      first LDS write (one memory latency).  Tile (0,0) goes straight into the registers of wave 0 in factor_tile's layout and
+    //      is factored from there while the other waves are still storing the rows below it: the first 16 pivots of the chain run
+    //      under the load instead of behind it.
+    const int nt = a.nt >= 1 && a.nt <= NB / 16 ? a.nt : NB / 16;
+    int nfix = 0;
     {
-        f64x2 v[16];
+        f64x4 t0 = (f64x4){0.0, 0.0, 0.0, 0.0};
+        if (wave == 0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            int idx = tid + u * PD_THREADS;
+            for (int q = 0; q < 4; ++q) t0[q] = a.Bkk[(int64_t)((lane >> 4) + 4 * q) * a.ld + (lane & 15)];
+        }
+        f64x2 v[14];
+#pragma unroll
+        for (int u = 0; u < 14; ++u) {
+            int idx = tid + (u + 2) * PD_THREADS;                   // rows 16 .. 127
             int i = idx >> 6, c2 = (idx & 63) * 2;
             v[u] = (c2 <= (i | 15)) ? *reinterpret_cast<const f64x2*>(a.Bkk + (int64_t)i * a.ld + c2) : (f64x2){0.0, 0.0};
         }
+        if (wave == 0) {
+            if (a.shift_rel != 0.0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            int idx = tid + u * PD_THREADS;
+                for (int q = 0; q < 4; ++q) if ((lane >> 4) + 4 * q == (lane & 15)) t0[q] += a.shift_rel * (*a.maxdiag);
+            }
+            nfix = factor_tile(W, 0, lane, thresh, a.big, dinv_s, &t0);
+        }
+#pragma unroll
+        for (int u = 0; u < 14; ++u) {
+            int idx = tid + (u + 2) * PD_THREADS;
             int i = idx >> 6, c2 = (idx & 63) * 2;
             if (c2 <= (i | 15)) *reinterpret_cast<f64x2*>(&W[i * WLD + c2]) = v[u];
         }
     }
-    const int nt = a.nt >= 1 && a.nt <= NB / 16 ? a.nt : NB / 16;
+    IPM_STAMP(2);
     if (nt < NB / 16) {
         // inverse rows of the padding part: X[i][j] = (i == j), stored at W[j][i + 1] (columns beyond the factored block)
         const int r0 = 16 * nt, nr = NB - r0;
@@ -443,33 +469,42 @@ __device__ __forceinline__ void potrf_diag_body(const PotrfDiag& a, double* W, d
     }
     if (a.shift_rel != 0.0) {
         __syncthreads();
-        if (tid < 16 * nt) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
+        if (tid >= 16 && tid < 16 * nt) W[tid * WLD + tid] += a.shift_rel * (*a.maxdiag);
     }
     __syncthreads();
     IPM_STAMP(1);
 
-    // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero from the handle's
-    //      initial memset and is never written).  Rows 0..111 of the inverse and all of L are final before the last
-    //      inverse row is assembled and are written under it (see potrf_lds); rows 112..127 of the inverse follow.
-    auto write_rows = [&](int u0, int u1, bool want_l, int inv_lo, int inv_hi) {
-        for (int u = u0; u < u1; ++u) {
-            int idx = tid + u * PD_THREADS;
-            int i = idx >> 6, j = (idx & 63) * 2;
-            if (j <= i) {
-                const bool wi = i >= inv_lo && i < inv_hi;
-                if (j + 1 <= i) {
-                    if (want_l) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){W[i * WLD + j], W[i * WLD + j + 1]};
-                    if (wi) *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){W[j * WLD + i + 1], W[(j + 1) * WLD + i + 1]};
-                } else {
-                    if (want_l) a.Bkk[(int64_t)i * a.ld + j] = W[i * WLD + j];
-                    if (wi) a.inv[i * NB + j] = W[j * WLD + i + 1];
+    // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero from the handle's initial
+    //      memset and is never written).  All of L and the inverse rows above the last tile row are final before
+    //      the last inverse row is assembled and are written under it (Hooks::last); the last tile row of the inverse and the
+    //      padding rows follow.  (Writing rows as soon as they are final, in the P3 phases from the fourth panel on where the
+    //      waves beside the pivot chain have slack, was measured in round 4: the end shrinks from 11.8k to 7.3k cycles and the
+    //      P3 phases grow by 3.9k -- the store path of the CU is the bound either way; profiles/r04_potrf_stamps.txt.)
+    struct Hooks {
+        const PotrfDiag& a; double* W; int nt, tid;
+        // rows 8 u0 .. 8 u1 - 1: L when want_l, the inverse where inv_lo <= row < inv_hi (every thread two columns of a row)
+        __device__ __forceinline__ void write_rows(int u0, int u1, bool want_l, int inv_lo, int inv_hi) const {
+            for (int u = u0; u < u1; ++u) {
+                int idx = tid + u * PD_THREADS;
+                int i = idx >> 6, j = (idx & 63) * 2;
+                if (j <= i) {
+                    const bool wi = i >= inv_lo && i < inv_hi;
+                    if (j + 1 <= i) {
+                        if (want_l) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){W[i * WLD + j], W[i * WLD + j + 1]};
+                        if (wi) *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){W[j * WLD + i + 1], W[(j + 1) * WLD + i + 1]};
+                    } else {
+                        if (want_l) a.Bkk[(int64_t)i * a.ld + j] = W[i * WLD + j];
+                        if (wi) a.inv[i * NB + j] = W[j * WLD + i + 1];
+                    }
                 }
             }
         }
+        __device__ __forceinline__ void panel(int, int, int) const {}
+        __device__ __forceinline__ void last() const { write_rows(0, 16, true, 0, 16 * (nt - 1)); }
     };
-    const int nfix = potrf_lds<STAMP>(W, dinv_s, nt, thresh, a.big, stamps,
-                                      [&]() { write_rows(0, 16, true, 0, 16 * (nt - 1)); });
-    write_rows(2 * (nt - 1), 16, false, 16 * (nt - 1), NB);   // (8 rows per u) the last factored tile row of the inverse and the padding rows
+    const Hooks hooks{a, W, nt, tid};
+    nfix += potrf_lds<STAMP>(W, dinv_s, nt, thresh, a.big, stamps, hooks, /*tile0_done=*/true);
+    hooks.write_rows(2 * (nt - 1), 16, false, 16 * (nt - 1), NB);   // (8 rows per u) the last factored tile row of the inverse and the padding rows
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
     if (a.signal) {

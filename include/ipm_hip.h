@@ -290,6 +290,12 @@ int ipm_debug_get_block_inverse(ipm_handle* h, int32_t k, double* out);
  * update: same}; out (capacity words) receives it when large enough; items (8 bytes each, may be NULL) the work list,
  * *nitems its length.  tools/ff_trace.py turns it into per-step stall tables. */
 int ipm_debug_ff_trace(ipm_handle* h, long long* out, int64_t capacity, int64_t* count, unsigned char* items, int32_t* nitems);
+/* Test hook (host only, no GPU): the schedule merge of the lockstep batch (csrc/lockstep_merge.h).  n launch programs, program i =
+ * types_flat[off[i] .. off[i+1]) (kernel types); aligned != 0: progressive alignment (the product's merge), 0: the leader rule it
+ * replaced.  out_steps (2 ints per step, capacity cap_steps steps): {type, member count}; out_members (2 ints per launch): {program,
+ * position} in step order.  Returns the number of steps, -1 on bad arguments / too small a capacity. */
+int ipm_debug_ls_merge(int32_t n, const int32_t* off, const int32_t* types_flat, int32_t max_group, int32_t aligned,
+                       int32_t* out_steps, int32_t cap_steps, int32_t* out_members);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ EXPORTS = [
     "ipm_create", "ipm_destroy", "ipm_last_error", "ipm_set_A_dense", "ipm_set_A_csc",
     "ipm_set_bc", "ipm_set_state", "ipm_get_state", "ipm_init_state", "ipm_newton_direction",
     "ipm_iterate", "ipm_solve", "ipm_solve_batch", "ipm_batch_create", "ipm_batch_destroy", "ipm_batch_last_error", "ipm_batch_add", "ipm_batch_step", "ipm_batch_stats", "ipm_get_history", "ipm_get_schedule", "ipm_order_rows", "ipm_get_factor_info", "ipm_solve_linear", "ipm_normal_solve", "ipm_form_normal_matrix", "ipm_get_factor",
-    "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps", "ipm_debug_ff_schedule", "ipm_debug_ff_trace", "ipm_debug_get_block_inverse",
+    "ipm_set_profiling", "ipm_get_phase_ms", "ipm_debug_get_stamps", "ipm_debug_ff_schedule", "ipm_debug_ff_trace", "ipm_debug_get_block_inverse", "ipm_debug_ls_merge",
 ]
 
 IPM_OK = 0
@@ -144,6 +144,7 @@ def load():
     lib.ipm_debug_ff_schedule.argtypes = [i32, i32, i32, C.POINTER(C.c_ubyte), i32, C.POINTER(i32), C.POINTER(i32), pd]
     lib.ipm_debug_get_block_inverse.argtypes = [vp, i32, pd]
     lib.ipm_debug_ff_trace.argtypes = [vp, C.POINTER(C.c_longlong), i64, C.POINTER(i64), C.POINTER(C.c_ubyte), C.POINTER(i32)]
+    lib.ipm_debug_ls_merge.argtypes = [i32, C.POINTER(i32), C.POINTER(i32), i32, i32, C.POINTER(i32), i32, C.POINTER(i32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("ipm_default_options", "ipm_last_error", "ipm_batch_last_error"):

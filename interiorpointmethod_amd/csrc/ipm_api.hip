@@ -30,6 +30,7 @@
 #include "vector_ops.h"
 #include "form_factor.h"
 #include "lockstep.h"
+#include "lockstep_merge.h"
 
 #include <algorithm>
 #include <atomic>
@@ -2436,34 +2437,45 @@ static int ls_record_program(ipm_handle* h, std::vector<LsLaunch>& prog) {
     return IPM_OK;
 }
 struct LsStep { int type; unsigned count, blocks, lds; size_t offset; };      // `count` records from `offset` on; blocks = sum of their grids
-// Merge the programs (each LP's order preserved) into global steps of one kernel type: the LP with the most launches left sets
-// the type of the next step, every LP whose next launch is of that type joins it.
+// Merge the programs (each LP's order preserved) into global steps of one kernel type (lockstep_merge.h: progressive alignment;
+// IPM_LS_MERGE=leader selects the first version for the A/B).
 static void ls_merge(const std::vector<const std::vector<LsLaunch>*>& progs, std::vector<LsStep>& steps, std::vector<LsRec>& recs) {
     steps.clear(); recs.clear();
-    const size_t n = progs.size();
-    std::vector<size_t> pos(n, 0);
-    for (;;) {
-        size_t lead = n, left = 0;
-        for (size_t i = 0; i < n; ++i) { const size_t l = progs[i]->size() - pos[i]; if (l > left) { left = l; lead = i; } }
-        if (lead == n) break;
+    std::vector<std::vector<int>> types(progs.size());
+    for (size_t i = 0; i < progs.size(); ++i) { types[i].reserve(progs[i]->size()); for (const LsLaunch& L : *progs[i]) types[i].push_back(L.type); }
+    static const bool leader = getenv("IPM_LS_MERGE") && !strcmp(getenv("IPM_LS_MERGE"), "leader");
+    std::vector<LsPlanStep> plan;
+    if (leader) ls_merge_leader(types, LS_MAX_GROUP, plan); else ls_merge_aligned(types, LS_MAX_GROUP, plan);
+    for (const LsPlanStep& ps : plan) {
         LsStep st;
-        st.type = (*progs[lead])[pos[lead]].type; st.count = 0; st.blocks = 0; st.lds = 0; st.offset = recs.size();
-        for (size_t i = 0; i < n; ++i) {
-            if (pos[i] >= progs[i]->size()) continue;
-            const LsLaunch& L = (*progs[i])[pos[i]];
-            if (L.type != st.type) continue;
-            if (st.count == (unsigned)LS_MAX_GROUP) {          // a launch serves at most LS_MAX_GROUP LPs: the rest of the group is the next step
-                steps.push_back(st);
-                st.count = 0; st.blocks = 0; st.lds = 0; st.offset = recs.size();
-            }
+        st.type = ps.type; st.count = 0; st.blocks = 0; st.lds = 0; st.offset = recs.size();
+        for (const auto& mb : ps.members) {
+            const LsLaunch& L = (*progs[(size_t)mb.first])[(size_t)mb.second];
             LsRec r = L.rec;
             r.start = st.blocks;
             recs.push_back(r);
             st.count++; st.blocks += L.rec.gridx; st.lds = std::max(st.lds, L.rec.lds);
-            ++pos[i];
         }
         steps.push_back(st);
     }
+}
+// Test hook (CPU): the merge alone.  n programs, program i = types[off[i] .. off[i+1]); aligned != 0: the progressive alignment,
+// 0: the leader rule.  out_steps (capacity cap_steps) receives {type, members} per step, out_members (capacity = total launches)
+// {program, position} per member in step order.  Returns the step count, or -1 when a capacity is too small.
+extern "C" int ipm_debug_ls_merge(int32_t n, const int32_t* off, const int32_t* types_flat, int32_t max_group, int32_t aligned,
+                                  int32_t* out_steps, int32_t cap_steps, int32_t* out_members) {
+    if (n < 0 || !off || (n > 0 && !types_flat) || max_group < 1) return -1;
+    std::vector<std::vector<int>> types((size_t)n);
+    for (int i = 0; i < n; ++i) types[(size_t)i].assign(types_flat + off[i], types_flat + off[i + 1]);
+    std::vector<LsPlanStep> plan;
+    if (aligned) ls_merge_aligned(types, max_group, plan); else ls_merge_leader(types, max_group, plan);
+    if ((int64_t)plan.size() > cap_steps) return -1;
+    size_t w = 0;
+    for (size_t s = 0; s < plan.size(); ++s) {
+        out_steps[2 * s] = plan[s].type; out_steps[2 * s + 1] = (int32_t)plan[s].members.size();
+        for (const auto& mb : plan[s].members) { out_members[2 * w] = mb.first; out_members[2 * w + 1] = mb.second; ++w; }
+    }
+    return (int)plan.size();
 }
 
 struct ipm_batch {

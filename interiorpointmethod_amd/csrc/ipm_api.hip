@@ -1406,6 +1406,7 @@ static int enqueue_factor(ipm_handle* h, bool use_env = false, int mid_step = -1
         pd.nt = potrf_panels(h, k);
         if (h->stamp_buf && k == 0) {
             pd.stamps = h->stamp_buf;
+            if (getenv("IPM_POTRF_SKIP")) pd.dbg_tag = (unsigned)atoi(getenv("IPM_POTRF_SKIP"));
             hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(1), dim3(PD_THREADS), 0, sm, pd);
         } else if (!ls_push(h, LS_POTRF, 1u, pd)) {
             hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(1), dim3(PD_THREADS), 0, sm, pd);

@@ -95,8 +95,8 @@ __device__ __forceinline__ double row_bcast(double v, int k) {
     union { double d; int i[2]; } u, r;
     u.d = v; r.d = 0.0;
     switch (k) {
-#define IPM_RB(K) case K: r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + K, 0xf, 0xf, false); \
-                          r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + K, 0xf, 0xf, false); break;
+#define IPM_RB(K) case K: r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0x150 + K, 0xf, 0xf, true); \
+                          r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0x150 + K, 0xf, 0xf, true); break;
         IPM_RB(0) IPM_RB(1) IPM_RB(2) IPM_RB(3) IPM_RB(4) IPM_RB(5) IPM_RB(6) IPM_RB(7)
         IPM_RB(8) IPM_RB(9) IPM_RB(10) IPM_RB(11) IPM_RB(12) IPM_RB(13) IPM_RB(14) IPM_RB(15)
 #undef IPM_RB
@@ -205,20 +205,30 @@ __device__ __forceinline__ void invert_tile(double* W, int c0, int lane, const d
     }
 }
 
-// Four rows of the panel below tile (c0,c0) per wave: lane (q, c) owns element c of row r0+q and keeps
+// Four rows of the panel below tile (c0,c0) per wave and GROUP: lane (q, c) owns element c of row r0+q and keeps
 // row c of the factored tile in registers with the entries k >= c ZEROED (trowm), so the column sweep is
 // branch- and select-free: x_k = p_k / L[k][k] comes from lane (q,k) by one DPP row broadcast, and
 // p_c -= x_k L[c][k] is a plain FMA for every lane (a no-op where k >= c).  p stays unscaled until the end.
 // 4 VALU operations per step instead of ~10 with the per-step selects.  Wave-level.
+// NG groups (rows r0 + 32 g + q: the wave's share of the panel, 8 waves x 4 rows apart) run through the sweep TOGETHER: their
+// chains are independent, so the 15 dependent steps of one hide under those of the others (one group at a time, the first panels
+// of a block spend 4 passes of ~1.1k cycles here; round 4).  Every row's arithmetic is what the one-group form does.
+template <int NG>
 __device__ __forceinline__ void substitute_rows4(double* W, int c0, int r0, int lane, const double* trowm, double dc) {
     const int q = lane >> 4, c = lane & 15;
-    double p = W[(r0 + q) * WLD + c0 + c];
+    double p[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) p[g] = W[(r0 + 32 * g + q) * WLD + c0 + c];
 #pragma unroll
     for (int k = 0; k < 15; ++k) {                           // column 15 has nothing to its right
-        const double xk = row_bcast(p * dc, k);
-        p = __builtin_fma(-xk, trowm[k], p);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const double xk = row_bcast(p[g] * dc, k);
+            p[g] = __builtin_fma(-xk, trowm[k], p[g]);
+        }
     }
-    W[(r0 + q) * WLD + c0 + c] = p * dc;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) W[(r0 + 32 * g + q) * WLD + c0 + c] = p[g] * dc;
 }
 
 // T(r0,q0) - L(r0, c0:c0+16) L(q0, c0:c0+16)^T kept in registers (accumulator layout), not written back.
@@ -258,10 +268,14 @@ __device__ __forceinline__ void update_tile(double* W, int c0, int r0, int q0, i
     for (int q = 0; q < 4; ++q) W[(r0 + fk + 4 * q) * WLD + q0 + fr] = acc0[q] + acc1[q];
 }
 
-// X(ib,jt) = -X(ib,ib) * sum_{k=jt}^{ib-1} L(ib,k) X(k,jt)  (tile indices).  Wave-level.
-__device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, int fk) {
-    f64x4 s0 = (f64x4){0.0, 0.0, 0.0, 0.0}, s1 = s0;
-    for (int kb = jt; kb < ib; ++kb) {
+// X(ib,jt) = -X(ib,ib) * sum_{k=jt}^{ib-1} L(ib,k) X(k,jt)  (tile indices).  Wave-level, in parts: the sum S over a range of k
+// (needs block row ib of L and the inverse rows kb of that range) with its two accumulators carried in registers, so a sum can be
+// started before the last inverse row above ib exists and continued behind a barrier with the SAME order of additions; then the
+// product with the diagonal tile's inverse (needs X(ib,ib)).
+struct InvSum { f64x4 s0, s1; };
+__device__ __forceinline__ InvSum inv_sum_zero() { InvSum z; z.s0 = (f64x4){0.0, 0.0, 0.0, 0.0}; z.s1 = z.s0; return z; }
+__device__ __forceinline__ void inverse_tile_accum(const double* W, int ib, int jt, int kb0, int kb1, int fr, int fk, InvSum& st) {
+    for (int kb = kb0; kb < kb1; ++kb) {
         double av[4], bv[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -269,12 +283,18 @@ __device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, 
             int kr = kb * 16 + kk * 4 + fk, cc = jt * 16 + fr;                          // X[kr][cc]
             bv[kk] = (kr >= cc) ? W[cc * WLD + kr + 1] : 0.0;
         }
-        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], s1, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], s1, 0, 0, 0);
+        st.s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], st.s0, 0, 0, 0);
+        st.s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], st.s1, 0, 0, 0);
+        st.s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], st.s0, 0, 0, 0);
+        st.s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], st.s1, 0, 0, 0);
     }
-    f64x4 s = s0 + s1;
+}
+__device__ __forceinline__ f64x4 inverse_tile_sum(const double* W, int ib, int jt, int fr, int fk) {
+    InvSum st = inv_sum_zero();
+    inverse_tile_accum(W, ib, jt, jt, ib, fr, fk, st);
+    return st.s0 + st.s1;
+}
+__device__ __forceinline__ void inverse_tile_finish(double* W, int ib, int jt, int fr, int fk, const f64x4 s) {
     // second product: accumulator register q of S is row fk+4q, so it pairs with X(ib,ib)[fr][fk+4q]
     double xa[4];
 #pragma unroll
@@ -291,6 +311,9 @@ __device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, 
     for (int q = 0; q < 4; ++q)                                                          // X(ib,jt)[fk+4q][fr]
         W[(jt * 16 + fr) * WLD + ib * 16 + fk + 4 * q + 1] = r0[q] + r1[q];
 }
+__device__ __forceinline__ void inverse_tile(double* W, int ib, int jt, int fr, int fk) {
+    inverse_tile_finish(W, ib, jt, fr, fk, inverse_tile_sum(W, ib, jt, fr, fk));
+}
 
 // STAMP = true is a diagnostic instantiation (tools/potrf_stamps.py): every wave records s_memtime
 // at each phase boundary into stamps[wave*64 + slot]; the production kernel carries no stamps.
@@ -303,12 +326,12 @@ constexpr int PD_THREADS = 512;      // 8 waves: wave 0 runs the serial pivot ch
 // have passed a barrier after the last write to W.  Returns the number of guarded pivots (meaningful on wave 0).
 // nt = 8 is the 128 x 128 diagonal block of the blocked factorization (potrf_diag_kernel); the fused small-LP kernel
 // (small_lp.h) calls it with nt = ceil(m / 16).
-// Hooks of potrf_lds for work that only READS what is already final (the write-back of potrf_diag_body): panel(jb, part, nparts) is
-// called in P3(jb) by every wave except the one on the pivot chain, behind its share of the panel's items (L rows of the tiles up
-// to jb and the inverse rows of the tiles up to jb-2 are final there); last() by every wave behind its tile of the last inverse row.
+// Hooks of potrf_lds for work that only READS what is already final (the write-back of potrf_diag_body): phase(jb, wave) is called in
+// P3(jb) by every wave that is not on the pivot chain, behind its items (the tile rows up to jb of L and up to jb-2 of the inverse
+// are final there); last() by every wave behind the products of the last inverse row (tile row nt-2 of the inverse is final there).
 struct NoEarlyWork {
-    __device__ __forceinline__ void panel(int, int, int) const {}
-    __device__ __forceinline__ void last() const {}
+    __device__ __forceinline__ void phase(int, int) const {}
+    __device__ __forceinline__ void last(int) const {}
 };
 
 // tile0_done: the caller has factored tile (0,0) itself (factor_tile with `pre`) and every wave has passed a barrier since.
@@ -332,6 +355,7 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
     //           wave 7 : invert tile jb, then shares the item list
     //           waves 1..6: item list = rest of the trailing update of panel jb, then block row jb-1 of
     //                       inv(L) (its diagonal tile inverse was produced in P3(jb-1))
+    InvSum sumA = inv_sum_zero();                          // last panel: the sum of this wave's tile of the last inverse row
     for (int jb = 0; jb < nt; ++jb) {
         const int c0 = jb * 16;
         const int nrt = nt - jb - 1;                      // 16-row tiles below the pivot tile
@@ -343,7 +367,12 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
                 trow[k] = (k < fr) ? v.x : 0.0; trow[k + 1] = (k + 1 < fr) ? v.y : 0.0;      // strictly lower part of row fr
             }
             const double dc = dinv_s[c0 + fr];
-            for (int g = wave; g < 4 * nrt; g += 8) substitute_rows4(W, c0, c0 + 16 + 4 * g, lane, trow, dc);
+            // groups wave, wave + 8, ... < 4 nrt of four rows each: all of this wave's groups in ONE sweep
+            const int ng = (4 * nrt - wave + 7) >> 3, r0 = c0 + 16 + 4 * wave;
+            if (ng >= 4) substitute_rows4<4>(W, c0, r0, lane, trow, dc);
+            else if (ng == 3) substitute_rows4<3>(W, c0, r0, lane, trow, dc);
+            else if (ng == 2) substitute_rows4<2>(W, c0, r0, lane, trow, dc);
+            else if (ng == 1) substitute_rows4<1>(W, c0, r0, lane, trow, dc);
         }
         IPM_STAMP(4 + jb * 4);
         __syncthreads();
@@ -354,37 +383,60 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
         } else {
             // items: update tiles 1..ntile-1 of panel jb, then tiles 0..jb-2 of inverse row jb-1.
             // Wave 7 only inverts tile jb (about as long as wave 0's factorization) while a pivot tile is
-            // left; the item list is shared by waves 1..6 (all 8 waves on the last panel).
-            const int ntile = nrt * (nrt + 1) / 2;
-            const int nupd = ntile > 0 ? ntile - 1 : 0;
-            const int ninv = jb >= 1 ? jb - 1 : 0;
-            const int nw = (nrt > 0) ? 6 : 8;
-            int me = (nrt > 0) ? wave - 1 : wave;
-            if (wave == 7) { invert_tile(W, c0, lane, dinv_s); if (nrt > 0) me = nupd + ninv; }
-            for (int it = me; it < nupd + ninv; it += nw) {
-                if (it < nupd) {
-                    int tix = it + 1;
-                    int ib = (int)((sqrtf(8.0f * (float)tix + 1.0f) - 1.0f) * 0.5f);
-                    while ((ib + 1) * (ib + 2) / 2 <= tix) ++ib;
-                    while (ib * (ib + 1) / 2 > tix) --ib;
-                    int cb = tix - ib * (ib + 1) / 2;
-                    update_tile(W, c0, (jb + 1 + ib) * 16, (jb + 1 + cb) * 16, fr, fk);
-                } else {
-                    inverse_tile(W, jb - 1, it - nupd, fr, fk);
+            // left; the item list is shared by waves 1..6.
+            if (nrt > 0) {
+                const int ntile = nrt * (nrt + 1) / 2;
+                const int nupd = ntile - 1;
+                const int ninv = jb >= 1 ? jb - 1 : 0;
+                int me = wave - 1;
+                if (wave == 7) { invert_tile(W, c0, lane, dinv_s); me = nupd + ninv; }
+                for (int it = me; it < nupd + ninv; it += 6) {
+                    if (it < nupd) {
+                        int tix = it + 1;
+                        int ib = (int)((sqrtf(8.0f * (float)tix + 1.0f) - 1.0f) * 0.5f);
+                        while ((ib + 1) * (ib + 2) / 2 <= tix) ++ib;
+                        while (ib * (ib + 1) / 2 > tix) --ib;
+                        int cb = tix - ib * (ib + 1) / 2;
+                        update_tile(W, c0, (jb + 1 + ib) * 16, (jb + 1 + cb) * 16, fr, fk);
+                    } else {
+                        inverse_tile(W, jb - 1, it - nupd, fr, fk);
+                    }
                 }
+                early.phase(jb, wave);
+            } else {
+                // LAST panel: nothing is left on the pivot chain but the inversion of the last diagonal tile (wave 7), and the last
+                // TWO block rows of inv(L) are still to come -- tile (nt-2, jt) costs nt-2-jt products, the sum of tile (nt-1, jt)
+                // one more, of which only the last needs row nt-2.  So both rows run here, balanced: with n = nt-2, wave w < n makes
+                // tile (nt-2, w) (n-w products) and the sum of tile (nt-1, n-1-w) up to row nt-3 (w+1 products), kept in registers;
+                // behind the barrier every sum takes its last term and the product with the tile inverse, one tile per wave.
+                // (One tile per wave in column order, first row nt-2 then row nt-1: 13 products on wave 0, 1 on wave 6, and an fp64
+                // MFMA is 64 cycles on a SIMD that two waves share: 11.5k + 6k cycles for the two rows, now 7 products per wave.)
+                if (wave == 7) invert_tile(W, c0, lane, dinv_s);
+                const int n = nt - 2;
+                if (wave < n) {
+                    inverse_tile(W, nt - 2, wave, fr, fk);
+                    inverse_tile_accum(W, nt - 1, n - 1 - wave, n - 1 - wave, nt - 2, fr, fk, sumA);
+                }
+                early.phase(jb, wave);
             }
-            early.panel(jb, (nrt > 0) ? wave - 1 : wave, (nrt > 0) ? 7 : 8);
         }
         IPM_STAMP(6 + jb * 4);
         __syncthreads();
         IPM_STAMP(7 + jb * 4);
     }
-    // last block row of inv(L): needs the tile inverse of the last panel (made in its P3) and the row above it.
-    // early.last() (optional): work that only READS what is already final -- L and the inverse rows above the last one -- runs
-    // here, per wave, right behind that wave's tile of the last row: the tiles are uneven (nt-1 ... 1 products), so what is left
-    // of the write-back of the blocked factorization hides under the longest of them instead of following it.
-    for (int jt = wave; jt < nt - 1; jt += 8) inverse_tile(W, nt - 1, jt, fr, fk);
-    early.last();
+    // last block row of inv(L): the sums (in registers, above) take their last term -- row nt-2 is complete behind the barrier --
+    // and the product with the last tile's inverse: X(nt-1, jt) = -X(nt-1, nt-1) S.
+    // early.last() (optional): work that only READS what is already final runs here, per wave, behind that.
+    {
+        const int n = nt - 2;
+        if (wave < n) {
+            inverse_tile_accum(W, nt - 1, n - 1 - wave, nt - 2, nt - 1, fr, fk, sumA);
+            inverse_tile_finish(W, nt - 1, n - 1 - wave, fr, fk, sumA.s0 + sumA.s1);
+        } else if (wave == n) {
+            inverse_tile(W, nt - 1, nt - 2, fr, fk);          // (one term: the tile inverse of row nt-2 is from the panel before)
+        }
+    }
+    early.last(wave);
     IPM_STAMP(38);
     __syncthreads();
     IPM_STAMP(39);
@@ -474,37 +526,127 @@ __device__ __forceinline__ void potrf_diag_body(const PotrfDiag& a, double* W, d
     __syncthreads();
     IPM_STAMP(1);
 
-    // ---- write back: L (lower) to B; inverse (lower; the strict upper triangle of `inv` stays zero from the handle's initial
-    //      memset and is never written).  All of L and the inverse rows above the last tile row are final before
-    //      the last inverse row is assembled and are written under it (Hooks::last); the last tile row of the inverse and the
-    //      padding rows follow.  (Writing rows as soon as they are final, in the P3 phases from the fourth panel on where the
-    //      waves beside the pivot chain have slack, was measured in round 4: the end shrinks from 11.8k to 7.3k cycles and the
-    //      P3 phases grow by 3.9k -- the store path of the CU is the bound either way; profiles/r04_potrf_stamps.txt.)
+    // ---- write back: L (lower) to B; inverse (lower triangle; above the diagonal only the zeros inside its 16 x 16 diagonal tiles
+    //      are written, the rest of the strict upper triangle of `inv` stays zero from the handle's initial memset).
+    //      One CU retires a global store INSTRUCTION every ~70 cycles whatever its width or mask (measured: 128 row-wise stores of
+    //      L from one wave 20k cycles; round-4 stamps), so the write-back is packed into as few full-wave 16-byte stores as the
+    //      triangle allows -- the short rows of L two, four and eight to an instruction (87 instead of ~190), the inverse two
+    //      instructions per 16 x 16 tile (72 instead of 144) -- and spread over the phases in which the waves beside the pivot chain
+    //      have slack: P3(jb), jb >= 3, takes tile row jb of L (the first one all rows before it too) and tile row jb-2 of the
+    //      inverse, dealt round-robin to waves 5..7; the last panel, where waves 0..5 make the last two inverse rows, the rest on
+    //      waves 6 and 7; tile row nt-2 of the inverse behind the last row's products, tile row nt-1 at the end.  (Before: all of
+    //      it behind the last inverse row, 13.5k cycles after the last panel of 88k in all.)
     struct Hooks {
-        const PotrfDiag& a; double* W; int nt, tid;
-        // rows 8 u0 .. 8 u1 - 1: L when want_l, the inverse where inv_lo <= row < inv_hi (every thread two columns of a row)
-        __device__ __forceinline__ void write_rows(int u0, int u1, bool want_l, int inv_lo, int inv_hi) const {
-            for (int u = u0; u < u1; ++u) {
-                int idx = tid + u * PD_THREADS;
-                int i = idx >> 6, j = (idx & 63) * 2;
-                if (j <= i) {
-                    const bool wi = i >= inv_lo && i < inv_hi;
-                    if (j + 1 <= i) {
-                        if (want_l) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = (f64x2){W[i * WLD + j], W[i * WLD + j + 1]};
-                        if (wi) *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){W[j * WLD + i + 1], W[(j + 1) * WLD + i + 1]};
-                    } else {
-                        if (want_l) a.Bkk[(int64_t)i * a.ld + j] = W[i * WLD + j];
-                        if (wi) a.inv[i * NB + j] = W[j * WLD + i + 1];
-                    }
-                }
+        const PotrfDiag& a; double* W; int nt, lane; unsigned skip;
+        // R = 8, 4, 2, 1 rows of L from row r in one instruction (64/R lanes per row, two columns per lane); the diagonal entry of
+        // an even row has no partner inside the triangle and is left to l_diag()
+        __device__ __forceinline__ void l_instr(int r, int lg) const {
+            if (skip & 1u) return;
+            const int lpr = 64 >> lg, i = r + (lane >> (6 - lg)), j = 2 * (lane & (lpr - 1));
+            const f64x2 v = *reinterpret_cast<const f64x2*>(&W[i * WLD + j]);
+            if (j + 1 <= i) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i * a.ld + j) = v;
+        }
+        // two of them with both LDS reads in flight before the first store (a unit alone is ~300 cycles of latency on its wave)
+        __device__ __forceinline__ void l_instr2(int r0, int r1, int lg) const {
+            if (skip & 1u) return;
+            const int lpr = 64 >> lg, sub = lane >> (6 - lg), j = 2 * (lane & (lpr - 1));
+            const int i0 = r0 + sub, i1 = r1 + sub;
+            const f64x2 v0 = *reinterpret_cast<const f64x2*>(&W[i0 * WLD + j]);
+            const f64x2 v1 = *reinterpret_cast<const f64x2*>(&W[i1 * WLD + j]);
+            if (j + 1 <= i0) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i0 * a.ld + j) = v0;
+            if (j + 1 <= i1) *reinterpret_cast<f64x2*>(a.Bkk + (int64_t)i1 * a.ld + j) = v1;
+        }
+        __device__ __forceinline__ void l_diag() const {
+            if (skip & 1u) return;
+            const int i = 2 * lane;
+            a.Bkk[(int64_t)i * a.ld + i] = W[i * WLD + i];
+        }
+        // rows 8 s .. 8 s + 7 of the 16 x 16 tile (ib, jt) of the inverse: X[i][j] sits TRANSPOSED at W[j][i+1]; lane (ri, cj) takes row
+        // ri, columns 2 cj and 2 cj + 1: LDS banks 8 cj + 2 ri (two lanes per bank pair, the minimum for 8-byte accesses)
+        __device__ __forceinline__ void inv_half(int ib, int jt, int sh) const {
+            if (skip & 2u) return;
+            const int i = 16 * ib + 8 * sh + (lane >> 3), j = 16 * jt + 2 * (lane & 7);
+            double x0 = W[j * WLD + i + 1], x1 = W[(j + 1) * WLD + i + 1];
+            if (ib == jt) { x0 = (j <= i) ? x0 : 0.0; x1 = (j + 1 <= i) ? x1 : 0.0; }
+            *reinterpret_cast<f64x2*>(a.inv + i * NB + j) = (f64x2){x0, x1};
+        }
+        __device__ __forceinline__ void inv_half2(int ib, int u0, int u1) const {      // units u = 2 jt + half of tile row ib
+            if (skip & 2u) return;
+            const int i0 = 16 * ib + 8 * (u0 & 1) + (lane >> 3), j0 = 16 * (u0 >> 1) + 2 * (lane & 7);
+            const int i1 = 16 * ib + 8 * (u1 & 1) + (lane >> 3), j1 = 16 * (u1 >> 1) + 2 * (lane & 7);
+            double x0 = W[j0 * WLD + i0 + 1], x1 = W[(j0 + 1) * WLD + i0 + 1];
+            double y0 = W[j1 * WLD + i1 + 1], y1 = W[(j1 + 1) * WLD + i1 + 1];
+            x0 = (j0 <= i0) ? x0 : 0.0; x1 = (j0 + 1 <= i0) ? x1 : 0.0;                 // (only the diagonal tile has j > i)
+            y0 = (j1 <= i1) ? y0 : 0.0; y1 = (j1 + 1 <= i1) ? y1 : 0.0;
+            *reinterpret_cast<f64x2*>(a.inv + i0 * NB + j0) = (f64x2){x0, x1};
+            *reinterpret_cast<f64x2*>(a.inv + i1 * NB + j1) = (f64x2){y0, y1};
+        }
+        // The instructions of a phase are dealt round-robin to its nw waves, segment by segment; wave `me` steps straight through
+        // ITS units (u = first, first + nw, ...): a wave issues an instruction every ~5 cycles, so a loop over all units of a phase
+        // with a test per unit costs more than the stores (measured: +4.6k cycles per phase).  `off` = units dealt so far mod nw.
+        struct Deal {
+            int me, nw, off;
+            __device__ __forceinline__ int first() const { const int f = me - off; return f < 0 ? f + nw : f; }
+            __device__ __forceinline__ void dealt(int count) {
+                off += count;
+                if (nw == 3) off -= 3 * ((off * 43) >> 7); else off &= nw - 1;       // nw is 3, 8 or 2; off < 128
+            }
+        };
+        __device__ __forceinline__ void l_segment(int r_lo, int r_hi, int lg, Deal& d) const {      // rows of one packing
+            if (r_hi <= r_lo) return;
+            const int count = (r_hi - r_lo) >> lg;
+            int u = d.first();
+            for (; u + d.nw < count; u += 2 * d.nw) l_instr2(r_lo + (u << lg), r_lo + ((u + d.nw) << lg), lg);
+            if (u < count) l_instr(r_lo + (u << lg), lg);
+            d.dealt(count);
+        }
+        __device__ __forceinline__ void l_rows(int r_lo, int r_hi, Deal& d) const {                 // r_lo, r_hi: multiples of 16
+            if (r_lo >= 64) { l_segment(r_lo, r_hi, 0, d); return; }
+            l_segment(r_lo, r_hi < 16 ? r_hi : 16, 3, d);
+            l_segment(r_lo > 16 ? r_lo : 16, r_hi < 32 ? r_hi : 32, 2, d);
+            l_segment(r_lo > 32 ? r_lo : 32, r_hi < 64 ? r_hi : 64, 1, d);
+            l_segment(r_lo > 64 ? r_lo : 64, r_hi, 0, d);
+        }
+        __device__ __forceinline__ void inv_rows(int ib_lo, int ib_hi, Deal& d) const {
+            for (int ib = ib_lo; ib < ib_hi; ++ib) {
+                const int count = 2 * (ib + 1);
+                int u = d.first();
+                for (; u + d.nw < count; u += 2 * d.nw) inv_half2(ib, u, u + d.nw);
+                if (u < count) inv_half(ib, u >> 1, u & 1);
+                d.dealt(count);
             }
         }
-        __device__ __forceinline__ void panel(int, int, int) const {}
-        __device__ __forceinline__ void last() const { write_rows(0, 16, true, 0, 16 * (nt - 1)); }
+        __device__ __forceinline__ void phase(int jb, int wave) const {
+            const int first = nt - 1 < 3 ? nt - 1 : 3;
+            if (jb < first) return;
+            const bool lastp = jb == nt - 1;
+            Deal d;
+            d.off = 0;
+            if (!lastp) { d.me = wave - 5; d.nw = 3; }                   // waves 5, 6, 7: the ones with the shortest items in every panel
+            else if (nt < NB / 16) { d.me = wave; d.nw = 8; }            // partial block: fewer products, more (padding) rows: all waves
+            else { d.me = wave - 6; d.nw = 2; }                          // waves 0..5 are busy with the last two inverse rows
+            if (d.me < 0) return;
+            l_rows(jb == first ? 0 : 16 * jb, 16 * (jb + 1), d);
+            if (lastp) {
+                l_rows(16 * nt, NB, d);
+                if (d.first() == 0) l_diag();
+                d.dealt(1);
+            }
+            inv_rows(jb == first ? 0 : jb - 2, jb - 1, d);
+            if (lastp) inv_rows(nt, NB / 16, d);
+        }
+        __device__ __forceinline__ void last(int wave) const {          // tile row nt-2 of the inverse
+            Deal d{wave, 8, 0};
+            if (nt >= 2) inv_rows(nt - 2, nt - 1, d);
+        }
+        __device__ __forceinline__ void end(int wave) const {           // tile row nt-1
+            Deal d{wave, 8, 0};
+            inv_rows(nt - 1, nt, d);
+        }
     };
-    const Hooks hooks{a, W, nt, tid};
+    const Hooks hooks{a, W, nt, lane, STAMP ? a.dbg_tag : 0u};      // (skip: timing experiments of the diagnostic build)
     nfix += potrf_lds<STAMP>(W, dinv_s, nt, thresh, a.big, stamps, hooks, /*tile0_done=*/true);
-    hooks.write_rows(2 * (nt - 1), 16, false, 16 * (nt - 1), NB);   // (8 rows per u) the last factored tile row of the inverse and the padding rows
+    hooks.end(wave);
     IPM_STAMP(40);
     if (lane == 0 && wave == 0 && nfix) atomicAdd(a.fixed, nfix);
     if (a.signal) {

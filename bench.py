@@ -416,6 +416,14 @@ def cpu_baseline_subset(cb, subset):
                       "%d converged in %.1f s" % (len(nm), conv, dt), "sample_names": nm}
 
 
+def lockstep_mode(lockstep=True, start="reference"):
+    """run_batch's lockstep argument: IPM_LOCKSTEP=0 never, =1 always, unset: "auto" (batch.lockstep_wanted)."""
+    env = os.environ.get("IPM_LOCKSTEP", "auto")
+    if not lockstep or start != "reference" or env == "0":
+        return False
+    return True if env == "1" else "auto"
+
+
 def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, workers=2, schedule="dynamic",
                start="reference", regularize=0.0, general=False, lockstep=True):
     """Timed batched solve of the set -> (records, elapsed seconds incl. the gather, max over ranks)."""
@@ -435,7 +443,7 @@ def run_netlib(names, probs, flops, dev, dist=None, red_dev="cuda", store=None, 
                              collective_at_world_one=bool(os.environ.get("IPM_BENCH_FORCE_DIST")),
                              gather_device=torch.device("cuda", dev) if (dist is not None and red_dev == "cuda") else None,
                              tol=1e-8, regularize=regularize, workers=workers, schedule=schedule, start=start,
-                             lockstep=(lockstep and start == "reference" and os.environ.get("IPM_LOCKSTEP", "1") != "0"),
+                             lockstep=lockstep_mode(lockstep, start),
                              # the general-form driver's own settings: e3 = 1e-6, at most 999 iterations (main.py:1088-1127)
                              **(dict(max_iter=999, tol_gap=1e-6) if general else dict(max_iter=300)))
     torch.cuda.synchronize()
@@ -484,7 +492,7 @@ def netlib_main(args):
                "config": {"workload": "Netlib %s set, %d LPs over %d GPU(s), %s; per GPU %s" % (
                    args.netlib_set, len(names), max(world, 1), sched,
                    "lockstep batches by size class (iteration k of the LPs of a class in the same launches), %d set-up threads" % max(1, args.workers)
-                   if (args.start == "reference" and os.environ.get("IPM_LOCKSTEP", "1") != "0" and args.workers > 1)
+                   if batch.lockstep_wanted(probs, max(world, 1), args.workers, lockstep_mode(True, args.start))
                    else "%d LP(s) in flight on separate streams" % max(1, args.workers))},
                "roofline": netlib_roofline(names, probs, flops, rec, elapsed, world),
                "summary": summ, "wall_seconds": elapsed, "regularize": args.regularize, "start_point": args.start,
@@ -691,7 +699,8 @@ def main():
                     names, probs, flops = [names[i] for i in keep], [probs[i] for i in keep], [flops[i] for i in keep]
                 rec, el = run_netlib(names, probs, flops, dev, workers=8)
                 summ = batch.summarize(rec)
-                out[key] = {"metric": "Netlib LPs/sec (%s, tol=1e-8, cap 300, lockstep batches by size class)" % label,
+                mode = ("lockstep batches by size class" if batch.lockstep_wanted(probs, 1, 8, lockstep_mode()) else "8 LPs in flight on separate streams")
+                out[key] = {"metric": "Netlib LPs/sec (%s, tol=1e-8, cap 300, %s)" % (label, mode),
                             "value": summ["converged"] / el, "unit": "LPs/s", "n_gpus": 1, "wall_seconds": el,
                             "summary": summ, "roofline": netlib_roofline(names, probs, flops, rec, el, 1),
                             "per_lp": per_lp_table(names, rec)}

@@ -434,6 +434,24 @@ def _gather_sparse(rec, dist, device=None):
     return out
 
 
+# "auto": the lockstep batches pay off when a GPU holds many more LPs of the dense-tile size range than the four hardware queues can
+# overlap as separate chains (73-LP suite, 61 such LPs on one GPU: 23.5 LPs/s against 14.7 one-at-a-time); with few of them the
+# chains of a batch only wait for each other (26-LP parity set, 17 such LPs: 86-123 LPs/s against 116-140) -- sweeps in
+# profiles/r04_netlib_lockstep_vs_classic_sweep.txt.  The rule counts LPs of more than 128 rows per rank.
+LOCKSTEP_MIN_LPS = int(__import__("os").environ.get("IPM_LOCKSTEP_MIN_LPS", 24))
+
+
+def lockstep_wanted(problems, world=1, workers=8, mode="auto"):
+    """Whether run_batch(lockstep=mode) uses the lockstep batches: the same answer on every rank."""
+    if mode in (False, None, 0, "0"):
+        return False
+    if workers <= 1:
+        return False
+    if mode == "auto":
+        return sum(1 for p in problems if p[0].shape[0] > 128) >= LOCKSTEP_MIN_LPS * max(1, world)
+    return True
+
+
 def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, solve_fn=solve_one, workers=1,
               schedule="static", store=None, collective_at_world_one=False, lockstep=False, **kw):
     """Shard `problems` (list of (A, b, c)) over the ranks of `dist`, solve, gather statistics.
@@ -455,7 +473,8 @@ def run_batch(problems, costs=None, device=0, dist=None, gather_device=None, sol
         costs = [predicted_cost(p[0].shape[0], p[0].shape[1]) for p in problems]
     # lockstep=True: each rank solves its shard of the static partition with the lockstep batch (solve_shard_lockstep): the ranks'
     # wall times are then set by their longest LP, which a pull-based schedule cannot improve
-    lockstep = bool(lockstep) and solve_fn is solve_one and workers > 1
+    # (lockstep="auto": only where a rank holds enough LPs for it, see LOCKSTEP_MIN_LPS)
+    lockstep = solve_fn is solve_one and lockstep_wanted(problems, world, workers, lockstep)
     store = store if (multi and schedule == "dynamic" and not lockstep) else None
     t0 = time.perf_counter()
     if store is not None:

@@ -2636,8 +2636,9 @@ extern "C" int ipm_batch_step(ipm_batch* b, int32_t* finished, int32_t cap, int3
     if (getenv("IPM_LS_DEBUG") && atoi(getenv("IPM_LS_DEBUG")) >= 2) {
         size_t longest = 0, lead = 0;
         for (int i : b->active) if (b->prog[(size_t)i].size() > longest) { longest = b->prog[(size_t)i].size(); lead = (size_t)i; }
-        fprintf(stderr, "[lockstep chunk] batch %p: %zu active, %zu steps (longest program %zu: %d rows), %.3f ms per iteration\n", (void*)b, b->active.size(),
-                b->steps.size(), longest, (int)b->hs[lead]->m, 1e3 * secs(t_mid) / b->chunk);
+        static const auto t_proc = std::chrono::steady_clock::now();      // (first chunk of the process = 0)
+        fprintf(stderr, "[lockstep chunk] t=%.3f s batch %p: %zu active, %zu steps (longest program %zu: %d rows), %.3f ms per iteration\n", secs(t_proc), (void*)b,
+                b->active.size(), b->steps.size(), longest, (int)b->hs[lead]->m, 1e3 * secs(t_mid) / b->chunk);
     }
     std::vector<int> keep;
     for (int i : b->active) {

@@ -207,3 +207,18 @@ def test_bench_compact_line_fits_the_driver_tail():
               vs_baseline=None, dtype="f64", data="netlib fixtures", config={"workload": "Netlib all"})
     c2 = json.loads(bench.compact_line(nl))
     assert c2["summary"]["converged"] == 35 and len(json.dumps(c2)) < 2048
+
+
+def test_lockstep_rule_is_the_same_on_every_rank():
+    """run_batch(lockstep="auto") takes the lockstep batches only where a rank holds enough LPs of more than 128 rows
+    (batch.lockstep_wanted; the driver loop being batched: script.py:147-173 of the reference)."""
+    import scipy.sparse as sp
+    from interiorpointmethod_amd import batch
+    mk = lambda m: (sp.eye(m, m + 3, format="csc"), np.ones(m), np.ones(m + 3))     # noqa: E731
+    many = [mk(200 + i) for i in range(batch.LOCKSTEP_MIN_LPS)] + [mk(20)] * 5
+    few = many[1:]
+    assert batch.lockstep_wanted(many, world=1, workers=8, mode="auto")
+    assert not batch.lockstep_wanted(few, world=1, workers=8, mode="auto")        # small LPs do not count
+    assert not batch.lockstep_wanted(many, world=2, workers=8, mode="auto")       # half of them per rank
+    assert not batch.lockstep_wanted(many, world=1, workers=1, mode="auto")       # nothing to overlap
+    assert batch.lockstep_wanted(few, world=1, workers=8, mode=True) and not batch.lockstep_wanted(many, world=1, workers=8, mode=False)

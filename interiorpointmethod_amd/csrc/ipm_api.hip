@@ -1540,6 +1540,14 @@ static bool ff_ok(const ipm_handle* h) {
 // schedule + device buffers, once per handle
 static int ff_build(ipm_handle* h) {
     if (h->ff_built) return IPM_OK;
+    {
+        // the work list, its calibration and the one-workgroup-per-CU launch are those of a whole MI355X (gfx950, 256 CUs): on any other
+        // device (another part, a partition) the handle keeps the serial path unless the fused one is forced (IPM_FUSED_FACTOR=force)
+        hipDeviceProp_t prop;
+        HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
+        if (!h->ff_forced && (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.multiProcessorCount != 256))
+            return fail(h, IPM_ERR_STATE, "fused factor: built for a 256-CU gfx950 device (this one: %s, %d CUs)", prop.gcnArchName, prop.multiProcessorCount);
+    }
     if (h->ff_workers <= 0) {
         hipDeviceProp_t prop;
         HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));

@@ -205,30 +205,21 @@ __device__ __forceinline__ void invert_tile(double* W, int c0, int lane, const d
     }
 }
 
-// Four rows of the panel below tile (c0,c0) per wave and GROUP: lane (q, c) owns element c of row r0+q and keeps
+// Four rows of the panel below tile (c0,c0) per wave: lane (q, c) owns element c of row r0+q and keeps
 // row c of the factored tile in registers with the entries k >= c ZEROED (trowm), so the column sweep is
 // branch- and select-free: x_k = p_k / L[k][k] comes from lane (q,k) by one DPP row broadcast, and
 // p_c -= x_k L[c][k] is a plain FMA for every lane (a no-op where k >= c).  p stays unscaled until the end.
-// 4 VALU operations per step instead of ~10 with the per-step selects.  Wave-level.
-// NG groups (rows r0 + 32 g + q: the wave's share of the panel, 8 waves x 4 rows apart) run through the sweep TOGETHER: their
-// chains are independent, so the 15 dependent steps of one hide under those of the others (one group at a time, the first panels
-// of a block spend 4 passes of ~1.1k cycles here; round 4).  Every row's arithmetic is what the one-group form does.
-template <int NG>
+// 4 VALU operations per step (scale, two DPP moves, FMA): a sweep is ISSUE bound, which is why running a wave's groups through
+// it together instead of one after the other changes nothing (measured in rounds 3 and 4).  Wave-level.
 __device__ __forceinline__ void substitute_rows4(double* W, int c0, int r0, int lane, const double* trowm, double dc) {
     const int q = lane >> 4, c = lane & 15;
-    double p[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) p[g] = W[(r0 + 32 * g + q) * WLD + c0 + c];
+    double p = W[(r0 + q) * WLD + c0 + c];
 #pragma unroll
     for (int k = 0; k < 15; ++k) {                           // column 15 has nothing to its right
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const double xk = row_bcast(p[g] * dc, k);
-            p[g] = __builtin_fma(-xk, trowm[k], p[g]);
-        }
+        const double xk = row_bcast(p * dc, k);
+        p = __builtin_fma(-xk, trowm[k], p);
     }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) W[(r0 + 32 * g + q) * WLD + c0 + c] = p[g] * dc;
+    W[(r0 + q) * WLD + c0 + c] = p * dc;
 }
 
 // T(r0,q0) - L(r0, c0:c0+16) L(q0, c0:c0+16)^T kept in registers (accumulator layout), not written back.
@@ -367,12 +358,7 @@ __device__ __forceinline__ int potrf_lds(double* W, double* dinv_s, int nt, doub
                 trow[k] = (k < fr) ? v.x : 0.0; trow[k + 1] = (k + 1 < fr) ? v.y : 0.0;      // strictly lower part of row fr
             }
             const double dc = dinv_s[c0 + fr];
-            // groups wave, wave + 8, ... < 4 nrt of four rows each: all of this wave's groups in ONE sweep
-            const int ng = (4 * nrt - wave + 7) >> 3, r0 = c0 + 16 + 4 * wave;
-            if (ng >= 4) substitute_rows4<4>(W, c0, r0, lane, trow, dc);
-            else if (ng == 3) substitute_rows4<3>(W, c0, r0, lane, trow, dc);
-            else if (ng == 2) substitute_rows4<2>(W, c0, r0, lane, trow, dc);
-            else if (ng == 1) substitute_rows4<1>(W, c0, r0, lane, trow, dc);
+            for (int g = wave; g < 4 * nrt; g += 8) substitute_rows4(W, c0, c0 + 16 + 4 * g, lane, trow, dc);
         }
         IPM_STAMP(4 + jb * 4);
         __syncthreads();

@@ -1,23 +1,24 @@
 // form_factor.h -- FUSED formation + factorization for dense handles (gfx950): B = A diag(d) A^T (main.py:224 of the
-// reference) and everything of its blocked Cholesky (the factorization inside main.py:180 / :226) EXCEPT the pivot chain,
-// in ONE persistent launch that runs BESIDE the pivot chain instead of before it.
+// reference) and ALL of its blocked Cholesky (the factorization inside main.py:180 / :226), the pivot chain included, in ONE
+// persistent launch of as many workgroups as the device has CUs (form_factor_roles_kernel).
 //
 // Why.  Formation (2.15 ms at 4096 x 8192) and factorization (2.14 ms) used to be strictly serial, although the
 // factorization is a latency chain of 32 x (potrf_diag + two small GEMMs) that keeps a handful of CUs busy.  Two things are
-// needed to overlap them: whole CUs that the chain kernels can always get, and a way to run the bulk
-// matrix work of the factorization (panel solves, trailing updates) with low latency while the formation saturates the chip.
-//   * CUs: this kernel's workgroups take 139 KB of LDS, so exactly one fits a CU, and it is launched with FEWER workgroups
-//     than the chip has CUs -- 224 of 256: workgroups are dealt to the XCDs and shader engines in a fixed rotation whatever
-//     is free, so EVERY shader engine (8 XCDs x 4) must keep one CU empty, or a chain kernel's workgroup can wait for ever
-//     behind persistent workers (tools/ff_reserve_probe.hip; 248 / 240 / 232 workers ran into the spin bound).  potrf_diag
-//     (133 KB of LDS) and the two critical GEMMs of every step run on the empty CUs at their solo pace.  No CU mask involved.
-//   * Bulk work: the workgroups are WORKERS that draw items from one ordered list (ff_schedule.h): formation chunks
-//     (a K range of a 256 x 128 PAIR of tiles, partial sums to slabs) interleaved with update / panel-solve items of the
-//     factorization, ordered so that what the chain needs next is always served first.  Formation commutes with the
-//     updates (tile = sum of slabs - sum_j L_ij L_cj^T), so the trailing updates do not wait for the formation.
-// Hand-offs between workers, and between workers and the chain kernels (other stream), are device counters under the
-// agent-scope release / acquire protocol of gemm_nt_f64.h; every spin is bounded (time-out word -> the host rolls the call
-// back and repeats it on the serial path).
+// needed to overlap them: a pivot chain that can always run, and a way to run the bulk matrix work of the
+// factorization (panel solves, trailing updates) with low latency while the formation saturates the chip.
+//   * Roles: every workgroup takes 139 KB of LDS (exactly one per CU) and first draws a role number from a counter: 0 = the pivot
+//     chain (ff_chain_role: potrf_diag_body per diagonal block in LDS), 1 .. 4 = the critical products of every step (ff_crit_role:
+//     32-row strips of L(k+1,k) and of the update of tile (k+1,k+1)), everybody else a worker.  Roles are claimed by workgroups
+//     that are RUNNING, so the chain is never the workgroup that did not get a CU, and no CU is kept free for anybody.  (Round 3
+//     ran the chain as separate launches on a second stream beside 224 workers and kept one CU per shader engine empty for
+//     them: workgroups are dealt to XCDs and engines in a fixed rotation whatever is free -- tools/ff_reserve_probe.hip; this
+//     structure is still selectable with IPM_FF_CHAIN_MODE=0 and is what form_factor_kernel + the chain launches of enqueue_form_factor do.)
+//   * Bulk work: the WORKERS draw items from one ordered list (ff_schedule.h): formation chunks (a K range of a 256 x 128 PAIR
+//     of tiles, partial sums to slabs) interleaved with update / panel-solve items of the factorization, in the start order of a
+//     bottom-level list scheduling of the item DAG.  Formation commutes with the updates (tile = sum of slabs - sum_j L_ij
+//     L_cj^T), so the trailing updates do not wait for the formation.
+// Hand-offs between the roles are device counters under the agent-scope release / acquire protocol of gemm_nt_f64.h; every
+// spin is bounded (time-out word -> the host rolls the call back and repeats it on the serial path).
 //
 // GEMM engines (8 waves, v_mfma_f64_16x16x4_f64): ff_gemm_pair for the formation -- 256 x 128 per workgroup, waves 4 (M) x 2 (N),
 // BK = 16 stages on the schedule of adat_syrk_kernel (0.87 of the fp64 MFMA peak standalone, tools/ff_gemm_bench.hip);

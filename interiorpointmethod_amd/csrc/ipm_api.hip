@@ -2048,8 +2048,21 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         if (gstep >= 0) {
             // the last group's inverse (nine dependent launches, ~80 us) goes to the residual stream as well: the forward
             // sweep of the predictor over the earlier groups runs beside it and only its last step waits
-            HIP_TRY(h, hipEventRecord(h->ev_grp, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
+            if (h->ff_last && h->ff_chain_mode) {
+                // fused launch: the residual stream does not wait for an EVENT behind the launch (in the kernel trace both streams
+                // then resumed 45 us after the launch's last wave: two streams waiting for each other's events) but for the chain's
+                // last hand-off word, like the gate of the earlier groups: behind it the whole factor is released at agent scope
+                // (every worker's writes through the tile counters the chain acquired), and every kernel of a stream starts with an
+                // acquire.  The last group's inverse now starts 2 us after the launch ends, the main stream's sweep 11 us
+                // (profiles/r04_dense_iteration_timeline*.txt): 261.3 -> 262.4 it/s.
+                unsigned* F = h->d_ff_flags;
+                const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
+                unsigned* potrfdone = F + 32 + 2 * ntile + 2 * (size_t)h->nblk;
+                hipLaunchKernelGGL(ff_gate_kernel, dim3(1), dim3(64), 0, h->stream3, potrfdone + (h->nblk - 1), 1u, h->d_flags + 2 * (size_t)h->nblk, &h->sc->done);
+            } else {
+                HIP_TRY(h, hipEventRecord(h->ev_grp, h->stream));
+                HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
+            }
             if ((rc = enqueue_group_inverses(h, nG - 1, nG, h->stream3))) return rc;
             HIP_TRY(h, hipEventRecord(h->ev_last, h->stream3));
             HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_res, 0));

@@ -208,7 +208,7 @@ int ipm_solve_batch(ipm_handle** handles, int32_t n, double tol_p, double tol_d,
  * of a finished handle.  A batch owns one stream; it is not thread-safe; the handles stay owned by the caller and must outlive their
  * part in the batch (destroy a handle only after ipm_batch_step reported it finished, or after ipm_batch_destroy). */
 typedef struct ipm_batch ipm_batch;
-int ipm_batch_create(int device, ipm_batch** out);
+int ipm_batch_create(int device, void* stream, ipm_batch** out);   /* stream: a hipStream_t of the caller (kept alive until ipm_batch_destroy), or NULL: the batch creates its own */
 int ipm_batch_destroy(ipm_batch* b);
 const char* ipm_batch_last_error(const ipm_batch* b);
 int ipm_batch_add(ipm_batch* b, ipm_handle* h, double tol_p, double tol_d, double tol_gap, int32_t max_iter, int32_t* index);

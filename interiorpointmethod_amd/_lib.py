@@ -123,7 +123,7 @@ def load():
     lib.ipm_iterate.argtypes = [vp, i32, C.POINTER(Stats)]
     lib.ipm_solve.argtypes = [vp, dbl, dbl, dbl, i32, C.POINTER(Stats)]
     lib.ipm_solve_batch.argtypes = [C.POINTER(vp), i32, dbl, dbl, dbl, i32, C.POINTER(Stats)]
-    lib.ipm_batch_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.ipm_batch_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.ipm_batch_destroy.argtypes = [vp]
     lib.ipm_batch_last_error.argtypes = [vp]
     lib.ipm_batch_last_error.restype = C.c_char_p

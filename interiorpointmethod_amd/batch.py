@@ -124,13 +124,24 @@ def solve_shard(problems, ids, device=0, solve_fn=solve_one, workers=1, **kw):
     each solve alone is 10-25 % slower without the look-ahead.  Results do not depend on the interleaving (every handle
     is independent and deterministic, and both schedules perform the same arithmetic)."""
     rec = np.zeros((len(ids), NF), dtype=np.float64)
+    import queue
+    free_streams = queue.Queue()        # the rank's worker streams, the same ones in every call (see _lockstep_streams)
+    for st in _lockstep_streams(device, max(1, workers)):
+        free_streams.put(st)
+
+    def on_a_worker_stream(p, **k):
+        st = free_streams.get()
+        try:
+            return _in_own_stream(solve_fn, p, device, k, stream=st)
+        finally:
+            free_streams.put(st)
 
     def one(row_i):
         row, i = row_i
         t0 = time.perf_counter()
         if workers > 1 and problems[i][0].shape[0] <= SMALL_ROWS:
             # handles that share the GPU must not poll on the device (IPM_FLAG_NO_DEVICE_POLLING, include/ipm_hip.h)
-            info = _guarded(lambda p, **k: _in_own_stream(solve_fn, p, device, k), problems[i],
+            info = _guarded(on_a_worker_stream, problems[i],
                             **(dict(kw, concurrent=True) if solve_fn is solve_one else kw))
         else:
             info = _guarded(solve_fn, problems[i], device=device, **kw)
@@ -162,6 +173,26 @@ LOCKSTEP_CLASSES = [int(v) for v in __import__("os").environ.get("IPM_LOCKSTEP_C
 LOCKSTEP_CLASSIC_THREADS = int(__import__("os").environ.get("IPM_LOCKSTEP_CLASSIC_THREADS", 1))
 # up to this many rows an LP takes the dense-tile factor (and joins a batch) even where a lone solve would take the sparse one
 LOCKSTEP_DENSE_ROWS = int(__import__("os").environ.get("IPM_LOCKSTEP_DENSE_ROWS", 3500))
+
+
+_LOCKSTEP_STREAMS = {}      # device -> the streams of solve_shard_lockstep, created ONCE back to back
+
+
+def _lockstep_streams(device, n):
+    """n torch streams for the batches and the one-at-a-time runners of a rank, the same ones in every call.  HIP maps a new
+    stream onto the next of its four hardware queues in creation order: four streams created back to back sit on four
+    different queues, whereas streams created per call (and per finished batch) drift onto occupied ones -- the second and third
+    run of the suite in one process took 1.87 / 1.97 s instead of 1.41 (profiles/r04_netlib_repeated_runs_stream_reuse.txt)."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return [None] * n
+    except ImportError:
+        return [None] * n
+    have = _LOCKSTEP_STREAMS.setdefault(int(device), [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
 
 
 def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=5000, y0=1.0, regularize=0.0, tol_gap=None, **_):
@@ -225,15 +256,7 @@ def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=
         info.setdefault("seconds", time.perf_counter() - t0)
         rec[row] = _row(i, info)
 
-    def classic_runner():
-        own = None                      # ONE stream per runner for all its LPs: a new stream per LP walks through the hardware queues
-        if __import__("os").environ.get("IPM_LOCKSTEP_FIXED_STREAMS", "1") != "0":
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    own = torch.cuda.Stream(device=device)
-            except ImportError:
-                pass
+    def classic_runner(own):            # own: ONE stream per runner for all its LPs (a new stream per LP walks through the hardware queues)
         while True:
             item = classic_q.get()
             if item is None:
@@ -294,7 +317,7 @@ def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=
         if expected[k] == 0:
             return
         try:
-            with LockstepBatch(device=device, tol=tol, max_iter=max_iter, tol_gap=tol_gap) as lb:
+            with LockstepBatch(device=device, tol=tol, max_iter=max_iter, tol_gap=tol_gap, stream=streams[k]) as lb:
                 while arrived < expected[k] or lb.active > 0:
                     # every handle that is ready joins now; with nothing running, wait for the next one
                     while arrived < expected[k]:
@@ -327,10 +350,12 @@ def solve_shard_lockstep(problems, ids, device=0, workers=8, tol=1e-8, max_iter=
     def run_class_then_classic(k):
         run_class(k)
         if expected[k] and __import__("os").environ.get("IPM_LOCKSTEP_STEAL", "1") != "0":
-            classic_runner()            # its batch is finished, its stream idle: help with the LPs outside the batches
+            classic_runner(streams[k])  # its batch is finished, its stream idle: help with the LPs outside the batches
 
+    nclassic = max(1, LOCKSTEP_CLASSIC_THREADS)
+    streams = _lockstep_streams(device, ncls + nclassic)
     runners = [threading.Thread(target=run_class_then_classic, args=(k,)) for k in range(ncls)]
-    crunners = [threading.Thread(target=classic_runner) for _ in range(max(1, LOCKSTEP_CLASSIC_THREADS))]
+    crunners = [threading.Thread(target=classic_runner, args=(streams[ncls + j],)) for j in range(nclassic)]
     for t in runners + crunners:
         t.start()
     for f in futs:
@@ -394,7 +419,9 @@ def _solve_dynamic(problems, order, store, key, device, solve_fn, workers, **kw)
         with lock:
             return int(store.add(key, 1)) - 1
 
-    def loop(_):
+    streams = _lockstep_streams(device, max(1, workers))      # one fixed stream per worker loop, the same ones in every call
+
+    def loop(w):
         while True:
             j = take()
             if j >= n:
@@ -402,7 +429,7 @@ def _solve_dynamic(problems, order, store, key, device, solve_fn, workers, **kw)
             i = order[j]
             t0 = time.perf_counter()
             if workers > 1:
-                info = _guarded(lambda p, **k: _in_own_stream(solve_fn, p, device, k), problems[i],
+                info = _guarded(lambda p, **k: _in_own_stream(solve_fn, p, device, k, stream=streams[w]), problems[i],
                                 **(dict(kw, concurrent=True) if solve_fn is solve_one else kw))
             else:
                 info = _guarded(solve_fn, problems[i], device=device, **kw)

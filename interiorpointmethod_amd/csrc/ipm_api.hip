@@ -2503,6 +2503,7 @@ extern "C" int ipm_debug_ls_merge(int32_t n, const int32_t* off, const int32_t* 
 struct ipm_batch {
     int device = 0;
     hipStream_t S = nullptr;
+    bool own_stream = true;                            // S was created here (ipm_batch_create without a stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<ipm_handle*> hs;                       // in the order they were added
     std::vector<std::vector<LsLaunch>> prog;
@@ -2534,7 +2535,7 @@ static int bfail(ipm_batch* b, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return bfail((b), IPM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-extern "C" int ipm_batch_create(int device, ipm_batch** out) {
+extern "C" int ipm_batch_create(int device, void* stream, ipm_batch** out) {
     if (!out) return bfail(nullptr, IPM_ERR_INVALID_ARG, "ipm_batch_create: out is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -2542,7 +2543,8 @@ extern "C" int ipm_batch_create(int device, ipm_batch** out) {
     ipm_batch* b = new ipm_batch();
     b->device = device;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->S, hipStreamNonBlocking);
+    if (stream) { b->S = (hipStream_t)stream; b->own_stream = false; }          // the caller's stream (kept alive by the caller)
+    else if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->S, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&b->ev0);
     if (e == hipSuccess) e = hipEventCreate(&b->ev1);
     static std::atomic<bool> attr_set[MAX_DEVICES];
@@ -2550,7 +2552,7 @@ extern "C" int ipm_batch_create(int device, ipm_batch** out) {
         e = hipFuncSetAttribute((const void*)ls_adat_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_MAX_MP * 8);
         attr_set[device].store(true, std::memory_order_release);
     }
-    if (e != hipSuccess) { const int rc = bfail(nullptr, IPM_ERR_HIP, "ipm_batch_create: %s", hipGetErrorString(e)); if (b->S) (void)hipStreamDestroy(b->S); delete b; return rc; }
+    if (e != hipSuccess) { const int rc = bfail(nullptr, IPM_ERR_HIP, "ipm_batch_create: %s", hipGetErrorString(e)); if (b->S && b->own_stream) (void)hipStreamDestroy(b->S); delete b; return rc; }
     *out = b;
     return IPM_OK;
 }
@@ -2564,7 +2566,7 @@ extern "C" int ipm_batch_destroy(ipm_batch* b) {
     if (b->d_recs) dev_free(b->device, b->S, b->d_recs);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->S) { (void)hipStreamSynchronize(b->S); (void)hipStreamDestroy(b->S); }
+    if (b->S) { (void)hipStreamSynchronize(b->S); if (b->own_stream) (void)hipStreamDestroy(b->S); }
     delete b;
     return IPM_OK;
 }
@@ -2702,7 +2704,7 @@ extern "C" int ipm_solve_batch(ipm_handle** hs, int32_t n, double tol_p, double 
     if (!hs || n <= 0 || max_iter < 0) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: bad arguments");
     for (int i = 0; i < n; ++i) if (!hs[i]) return fail(nullptr, IPM_ERR_INVALID_ARG, "ipm_solve_batch: NULL handle");
     ipm_batch* b = nullptr;
-    int rc = ipm_batch_create(hs[0]->device, &b);
+    int rc = ipm_batch_create(hs[0]->device, nullptr, &b);
     if (rc) return rc;
     struct Guard { ipm_batch* b; ~Guard() { ipm_batch_destroy(b); } } guard{b};
     for (int i = 0; i < n && !rc; ++i) { rc = ipm_batch_add(b, hs[i], tol_p, tol_d, tol_gap, max_iter, nullptr); if (rc) snprintf(hs[i]->err, sizeof hs[i]->err, "%s", b->err); }

@@ -489,10 +489,12 @@ class LockstepBatch:
     steps; step() runs opt.check_every iterations of every active LP in the same launches and returns the solvers that finished,
     each with its statistics in solver.stats.  The solvers stay owned by the caller (close them after they are reported finished)."""
 
-    def __init__(self, device=0, tol=1e-8, max_iter=5000, tol_gap=None):
+    def __init__(self, device=0, tol=1e-8, max_iter=5000, tol_gap=None, stream=None):
+        """stream: a torch.cuda.Stream the batch's launches go to (the caller keeps it alive); None: a stream of the batch's own."""
         self._lib = _lib.load()
         self._b = C.c_void_p()
-        _lib.check(None, self._lib.ipm_batch_create(int(device), C.byref(self._b)))
+        self._stream = stream
+        _lib.check(None, self._lib.ipm_batch_create(int(device), C.c_void_p(stream.cuda_stream) if stream is not None else None, C.byref(self._b)))
         self.tol, self.max_iter, self.tol_gap = float(tol), int(max_iter), float(tol if tol_gap is None else tol_gap)
         self.solvers = []
         self.active = 0

@@ -949,6 +949,18 @@ def test_netlib_suite_batched_config4(golden_dir):
     same = (seq[:, 3] == par[:, 3]) | (np.isnan(seq[:, 3]) & np.isnan(par[:, 3]))
     assert np.array_equal(seq[:, 1:3], par[:, 1:3]) and np.all(same)
     assert batch.summarize(par)["total_iterations"] == batch.summarize(seq)["total_iterations"]
+    # what bench.py runs by default (lockstep="auto": with 61 LPs of more than 128 rows on one GPU the LOCKSTEP batches):
+    # the same LPs converge to the same objectives in the same number of iterations.  (Inside a batch an LP of up to 3500 rows takes
+    # the dense-tile factor even where a lone solve takes the sparse one, so the LPs that end at the cap or in NaN may do so after a
+    # different number of iterations; the bit-for-bit comparison of the same handle alone / in a batch is tests/test_gpu_lockstep.py.)
+    assert batch.lockstep_wanted(probs, world=1, workers=8, mode="auto")
+    lock, _ = batch.run_batch(probs, tol=1e-8, max_iter=300, workers=8, lockstep="auto")
+    assert np.array_equal(lock[:, 0], np.arange(73)) and set(lock[:, 1].tolist()) <= {1.0, 2.0, 3.0}
+    assert not lock[:, F.index("timeouts_recovered")].any() and not lock[:, F.index("serial_launches")].any()
+    assert {names[int(r[0])] for r in lock if r[1] == 1.0} == conv
+    for r, q in zip(lock, par):
+        if q[1] == 1.0:
+            assert abs(r[3] - q[3]) <= 1e-8 * max(1.0, abs(q[3])) and abs(r[2] - q[2]) <= 2, (names[int(r[0])], r[2:4], q[2:4])
 
 
 def test_results_table_against_reference_log(tmp_path):

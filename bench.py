@@ -116,7 +116,7 @@ def compact_line(out):
         c["roofline"]["kernel"] = _short(rf["kernel"], 40).split(" ")[0]
     if out.get("cpu_baseline"):
         c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind"))
-        c["cpu_baseline"]["sample"] = _short(out["cpu_baseline"].get("sample", ""), 120)
+        c["cpu_baseline"]["sample"] = _short(out["cpu_baseline"].get("sample", ""), 60)
     if out.get("cpu_baseline_reference_algorithm"):
         c["cpu_baseline_reference_algorithm"] = _pick(out["cpu_baseline_reference_algorithm"], ("value", "unit", "cores"))
     for k in ("objective_check", "objective_checked"):
@@ -134,6 +134,8 @@ def compact_line(out):
         e["roofline_frac"] = _r((nl.get("roofline") or {}).get("frac"))
         if nl.get("cpu_baseline"):
             e["cpu_baseline"] = _pick(nl["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        if nl.get("emulated_multi_gpu"):
+            e["emulated_multi_gpu"] = _pick(nl["emulated_multi_gpu"], ("world", "wall_seconds", "value", "converged"))
         c[key] = e
     # the netlib workload's own line (bench.py --workload netlib) carries these at top level
     if "summary" in out:
@@ -175,6 +177,32 @@ def makespan_fields(names, rec):
     import numpy as np
     i = int(np.argmax(rec[:, 7]))
     return {"projected_makespan_8gpu_s": float(rec[i, 7]), "slowest_lp": names[int(rec[i, 0])]}
+
+
+def emulated_multi_gpu(names, probs, flops, dev, world=8):
+    """What `world` GPUs would do with this set, MEASURED on one: the static LPT shards of batch.run_batch (the partition every rank
+    derives for itself) are solved one shard after the other on this GPU, each exactly as its rank would solve it (eight LPs in
+    flight; a shard is too small for the lockstep batches); the slowest shard is the wall of the multi-GPU run -- the ranks share
+    nothing but the final all-gather of 112-byte records.  (The dynamic schedule of a real run can only shorten it.)"""
+    from interiorpointmethod_amd import batch
+    costs = [batch.predicted_cost(p[0].shape[0], p[0].shape[1]) for p in probs]
+    shards = batch.lpt_partition(costs, world)
+    walls, conv, slowest = [], 0, None
+    for ids in shards:
+        if not ids:
+            walls.append(0.0)
+            continue
+        sub = [probs[i] for i in ids]
+        rec, el = run_netlib([names[i] for i in ids], sub, [flops[i] for i in ids], dev, workers=8)
+        conv += int((rec[:, 1] == 1.0).sum())
+        if el >= max(walls + [0.0]):
+            j = int(rec[:, 7].argmax())
+            slowest = names[ids[int(rec[j, 0])]]
+        walls.append(float(el))
+    wall = max(walls)
+    return {"world": world, "wall_seconds": wall, "value": conv / wall if wall > 0 else 0.0, "unit": "LPs/s", "converged": conv,
+            "shard_walls": walls, "slowest_lp_of_slowest_shard": slowest,
+            "how": "the %d static LPT shards solved one after the other on ONE GPU, each as its rank would; wall = slowest shard" % world}
 
 
 def _blas_threads():
@@ -524,6 +552,7 @@ def main():
     ap.add_argument("--netlib-set", default="all", choices=["all", "parity", "general"],
                     help="all 73 valid standard-form files, the 26 on which the reference converges, or the 72 general-form "
                          "files (benchmarks_full) through the general-form front end")
+    ap.add_argument("--emulate-world", type=int, default=8, help="Netlib: also solve the static shards of this many ranks one after the other on this GPU (0 = skip)")
     ap.add_argument("--netlib-reps", type=int, default=3, help="dense workload: runs of each Netlib leg of the default line (the median one is reported)")
     ap.add_argument("--max-m", type=int, default=1 << 30, help="netlib: skip LPs with more rows")
     ap.add_argument("--workers", type=int, default=8, help="netlib: LPs in flight per GPU, each on one stream (1 = strictly one at a time, with the look-ahead)")
@@ -717,6 +746,8 @@ def main():
                     cb["gpu_seconds_same_sample"] = float(sum(r[7] for r in rec if names[int(r[0])] in cb["sample_names"]))
                     out[key]["cpu_baseline"] = cb
                 out[key].update(makespan_fields(names, rec))
+                if key == "netlib_all" and args.emulate_world > 1:
+                    out[key]["emulated_multi_gpu"] = emulated_multi_gpu(names, probs, flops, dev, args.emulate_world)
         emit(out)
     sv.close()
     if dist is not None:

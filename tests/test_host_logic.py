@@ -182,6 +182,10 @@ def test_bench_compact_line_fits_the_driver_tail():
     assert len(json.dumps(full)) > 20000
     full["netlib_all"]["projected_makespan_8gpu_s"] = 1.4512345678
     full["netlib_all"]["slowest_lp"] = "80BAU3B"
+    for k in ("netlib_all", "netlib"):
+        full[k]["wall_seconds_runs"] = [1.4123456, 1.4234567, 1.4345678]
+    full["netlib_all"]["emulated_multi_gpu"] = {"world": 8, "wall_seconds": 0.71234567, "value": 49.1234567, "unit": "LPs/s", "converged": 35,
+                                                "shard_walls": [0.7] * 8, "slowest_lp_of_slowest_shard": "PILOT87", "how": "h" * 300}
     line = bench.compact_line(full)
     assert "\n" not in line and len(line) < 2048, len(line)
     c = json.loads(line)
@@ -196,6 +200,7 @@ def test_bench_compact_line_fits_the_driver_tail():
     assert c["netlib_all"]["converged"] == full["netlib_all"]["summary"]["converged"]
     assert c["netlib_all"]["projected_makespan_8gpu_s"] == pytest.approx(1.45123, rel=1e-4)
     assert "per_lp" not in c["netlib_all"] and "per_lp" not in c["netlib"]
+    assert c["netlib_all"]["emulated_multi_gpu"] == {"world": 8, "wall_seconds": 0.712346, "value": 49.1235, "converged": 35}
     # worst case: very long free-text fields and a thousand LPs
     full["config"]["workload"] = "w" * 5000
     full["cpu_baseline"]["sample"] = "s" * 5000

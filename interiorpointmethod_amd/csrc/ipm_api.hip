@@ -160,6 +160,7 @@ struct ipm_handle {
     int *d_rowptr = nullptr, *d_colind = nullptr, *d_colptr = nullptr, *d_rowind = nullptr;
     double *d_rval = nullptr, *d_cval = nullptr;
     long long* stamp_buf = nullptr;       // diagnostic only (IPM_POTRF_STAMPS=1)
+    unsigned* ff_potrfdone = nullptr;     // fused launch: the chain's hand-off words of the launch enqueued last (one per block)
     Scalars* sc = nullptr;
     IterRec* hist = nullptr;              // [HIST_CAP] per-iteration records (ring)
     double* snap = nullptr;               // roll-back copy of (x, y, s) + Scalars (poll time-out / auto-regularize restart)
@@ -1648,6 +1649,7 @@ static int enqueue_form_factor(ipm_handle* h, hipEvent_t* ev, int mid_step, int 
     unsigned *ticket = F, *mticket = F + 16, *dbg = F + 24, *fcount = F + 32, *tprog = fcount + ntile, *lfinal = tprog + ntile, *dready = lfinal + nblk,
              *potrfdone = dready + nblk;
     unsigned* timeout = h->d_flags + 2 * (size_t)nblk;
+    h->ff_potrfdone = potrfdone;                               // (the gate of the last group's inverses polls its last word: enqueue_iteration)
     HIP_TRY(h, hipMemsetAsync(F, 0, sizeof(unsigned) * h->ff_flag_words, sw));
     HIP_TRY(h, hipEventRecord(h->ev_fork, sw));
     if (!h->ff_chain_mode) HIP_TRY(h, hipStreamWaitEvent(sm, h->ev_fork, 0));
@@ -2048,17 +2050,14 @@ static int enqueue_iteration(ipm_handle* h, hipEvent_t* ev) {
         if (gstep >= 0) {
             // the last group's inverse (nine dependent launches, ~80 us) goes to the residual stream as well: the forward
             // sweep of the predictor over the earlier groups runs beside it and only its last step waits
-            if (h->ff_last && h->ff_chain_mode) {
+            if (h->ff_last && h->ff_chain_mode && h->ff_potrfdone) {
                 // fused launch: the residual stream does not wait for an EVENT behind the launch (in the kernel trace both streams
                 // then resumed 45 us after the launch's last wave: two streams waiting for each other's events) but for the chain's
                 // last hand-off word, like the gate of the earlier groups: behind it the whole factor is released at agent scope
                 // (every worker's writes through the tile counters the chain acquired), and every kernel of a stream starts with an
                 // acquire.  The last group's inverse now starts 2 us after the launch ends, the main stream's sweep 11 us
                 // (profiles/r04_dense_iteration_timeline*.txt): 261.3 -> 262.4 it/s.
-                unsigned* F = h->d_ff_flags;
-                const size_t ntile = (size_t)h->nblk * (h->nblk + 1) / 2;
-                unsigned* potrfdone = F + 32 + 2 * ntile + 2 * (size_t)h->nblk;
-                hipLaunchKernelGGL(ff_gate_kernel, dim3(1), dim3(64), 0, h->stream3, potrfdone + (h->nblk - 1), 1u, h->d_flags + 2 * (size_t)h->nblk, &h->sc->done);
+                hipLaunchKernelGGL(ff_gate_kernel, dim3(1), dim3(64), 0, h->stream3, h->ff_potrfdone + (h->nblk - 1), 1u, h->d_flags + 2 * (size_t)h->nblk, &h->sc->done);
             } else {
                 HIP_TRY(h, hipEventRecord(h->ev_grp, h->stream));
                 HIP_TRY(h, hipStreamWaitEvent(h->stream3, h->ev_grp, 0));
